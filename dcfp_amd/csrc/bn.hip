@@ -1,0 +1,368 @@
+// bn.hip — BatchNorm2d(+ReLU)(+residual) training forward/backward for NCHW fp32.
+// Replaces nn.BatchNorm2d / nn.ReLU(inplace) as used in the reference at
+// networks/backbone/resnet.py:26-33,41-56 and networks/tools/aspp.py:15-16,22-24.
+//
+// All four kernels are HBM-bound streams: 16-byte loads per lane, one (n,c) row
+// segment or one (c, chunk) slice per 256-thread block, wave-shuffle reductions,
+// per-block partials combined in a fixed order in fp64 (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct BnPlan {
+    int chunks;       // blocks per channel
+    int chunk_elems;  // elements (of the N*HW per-channel population) per block, multiple of 4
+};
+
+BnPlan bn_plan(int N, int C, int HW) {
+    const long long E = (long long)N * HW;
+    long long by_size = (E + 2047) / 2048;
+    long long by_grid = 4096 / (C > 0 ? C : 1);
+    if (by_grid < 1) by_grid = 1;
+    long long chunks = by_size < by_grid ? by_size : by_grid;
+    if (chunks < 1) chunks = 1;
+    long long ce = (E + chunks - 1) / chunks;
+    ce = (ce + 3) / 4 * 4;
+    chunks = (E + ce - 1) / ce;
+    if (chunks < 1) chunks = 1;
+    BnPlan p;
+    p.chunks = (int)chunks;
+    p.chunk_elems = (int)ce;
+    return p;
+}
+
+// ---- stats: shifted sums  S1 = sum(x-K), S2 = sum((x-K)^2), K = x[0,c,0]
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads)
+bn_stats_partial_kernel(const float* __restrict__ x, long long nstride, int HW, long long E,
+                        int chunk_elems, int chunks, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    const float* xc = x + (long long)c * HW;
+    const float K = xc[0];
+    const long long e0 = (long long)chunk * chunk_elems;
+    long long e1 = e0 + chunk_elems;
+    if (e1 > E) e1 = E;
+    float s1 = 0.f, s2 = 0.f;
+    if (VEC) {
+        for (long long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * kThreads) {
+            const long long n = e / HW;
+            const int i = (int)(e - n * HW);
+            const float4 v = *reinterpret_cast<const float4*>(xc + n * nstride + i);
+            const float a = v.x - K, b = v.y - K, cc = v.z - K, d = v.w - K;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += kThreads) {
+            const long long n = e / HW;
+            const int i = (int)(e - n * HW);
+            const float a = xc[n * nstride + i] - K;
+            s1 += a;
+            s2 += a * a;
+        }
+    }
+    const float t1 = block_sum_256(s1, red);
+    const float t2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+        part[((long long)c * chunks + chunk) * 2 + 0] = t1;
+        part[((long long)c * chunks + chunk) * 2 + 1] = t2;
+    }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ x, int HW, long long E, int C,
+                                      int chunks, const float* __restrict__ part,
+                                      float* __restrict__ mean, float* __restrict__ var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double S1 = 0.0, S2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        S1 += (double)part[((long long)c * chunks + k) * 2 + 0];
+        S2 += (double)part[((long long)c * chunks + k) * 2 + 1];
+    }
+    const double K = (double)x[(long long)c * HW];
+    const double m1 = S1 / (double)E;
+    double v = S2 / (double)E - m1 * m1;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)(K + m1);
+    var[c] = (float)v;
+}
+
+// ---- apply: one (n,c) row segment per block
+template <bool VEC>
+__global__ void __launch_bounds__(kThreads)
+bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                const float* __restrict__ var, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float eps, const float* __restrict__ res,
+                int relu, float* __restrict__ y, long long y_nstride, int C, int HW,
+                int colchunks, int cols_per_block) {
+    const long long row = blockIdx.x / colchunks;
+    const int chunk = blockIdx.x - (int)(row * colchunks);
+    const int n = (int)(row / C), c = (int)(row - (long long)n * C);
+    const float istd = 1.0f / sqrtf(var[c] + eps);
+    const float mu = mean[c], g = gamma[c], b = beta[c];
+    const float* xr = x + row * HW;
+    const float* rr = res ? res + row * HW : nullptr;
+    float* yr = y + (long long)n * y_nstride + (long long)c * HW;
+    const int i0 = chunk * cols_per_block;
+    int i1 = i0 + cols_per_block;
+    if (i1 > HW) i1 = HW;
+    if (VEC) {
+        for (int i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kThreads) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + i);
+            float4 o;
+            o.x = (v.x - mu) * istd * g + b;
+            o.y = (v.y - mu) * istd * g + b;
+            o.z = (v.z - mu) * istd * g + b;
+            o.w = (v.w - mu) * istd * g + b;
+            if (rr) {
+                const float4 r = *reinterpret_cast<const float4*>(rr + i);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            if (relu) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(yr + i) = o;
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += kThreads) {
+            float o = (xr[i] - mu) * istd * g + b;
+            if (rr) o += rr[i];
+            if (relu) o = o > 0.f ? o : 0.f;
+            yr[i] = o;
+        }
+    }
+}
+
+// ---- backward stage 1: S1 = sum g, S2 = sum g*(x-mean),  g = dy*(y>0)
+template <bool VEC, bool RELU>
+__global__ void __launch_bounds__(kThreads)
+bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
+                             const float* __restrict__ x, const float* __restrict__ y,
+                             long long y_nstride, const float* __restrict__ mean, int C, int HW,
+                             long long E, int chunk_elems, int chunks, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    const float mu = mean[c];
+    const long long e0 = (long long)chunk * chunk_elems;
+    long long e1 = e0 + chunk_elems;
+    if (e1 > E) e1 = E;
+    const long long coff = (long long)c * HW;
+    const long long x_nstride = (long long)C * HW;
+    float s1 = 0.f, s2 = 0.f;
+    if (VEC) {
+        for (long long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * kThreads) {
+            const long long n = e / HW;
+            const int i = (int)(e - n * HW);
+            float4 g = *reinterpret_cast<const float4*>(dy + n * dy_nstride + coff + i);
+            const float4 xv = *reinterpret_cast<const float4*>(x + n * x_nstride + coff + i);
+            if (RELU) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + n * y_nstride + coff + i);
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            s1 += (g.x + g.y) + (g.z + g.w);
+            s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+        }
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += kThreads) {
+            const long long n = e / HW;
+            const int i = (int)(e - n * HW);
+            float g = dy[n * dy_nstride + coff + i];
+            if (RELU) g = y[n * y_nstride + coff + i] > 0.f ? g : 0.f;
+            s1 += g;
+            s2 += g * (x[n * x_nstride + coff + i] - mu);
+        }
+    }
+    const float t1 = block_sum_256(s1, red);
+    const float t2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+        part[((long long)c * chunks + chunk) * 2 + 0] = t1;
+        part[((long long)c * chunks + chunk) * 2 + 1] = t2;
+    }
+}
+
+__global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict__ part,
+                                     float* __restrict__ o1, float* __restrict__ o2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double S1 = 0.0, S2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        S1 += (double)part[((long long)c * chunks + k) * 2 + 0];
+        S2 += (double)part[((long long)c * chunks + k) * 2 + 1];
+    }
+    o1[c] = (float)S1;
+    o2[c] = (float)S2;
+}
+
+// ---- backward stage 2
+template <bool VEC, bool RELU>
+__global__ void __launch_bounds__(kThreads)
+bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
+                    const float* __restrict__ x, const float* __restrict__ y,
+                    long long y_nstride, const float* __restrict__ mean,
+                    const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xmu,
+                    float inv_count, float* __restrict__ dx, float* __restrict__ dres, int C,
+                    int HW, int colchunks, int cols_per_block) {
+    const long long row = blockIdx.x / colchunks;
+    const int chunk = blockIdx.x - (int)(row * colchunks);
+    const int n = (int)(row / C), c = (int)(row - (long long)n * C);
+    const float istd = 1.0f / sqrtf(var[c] + eps);
+    const float mu = mean[c];
+    const float mean_dy = sum_dy[c] * inv_count;
+    const float k = sum_dy_xmu[c] * inv_count * istd * istd;
+    const float gi = gamma[c] * istd;
+    const float* dyr = dy + (long long)n * dy_nstride + (long long)c * HW;
+    const float* xr = x + row * HW;
+    const float* yr = RELU ? y + (long long)n * y_nstride + (long long)c * HW : nullptr;
+    float* dxr = dx + row * HW;
+    float* drr = dres ? dres + row * HW : nullptr;
+    const int i0 = chunk * cols_per_block;
+    int i1 = i0 + cols_per_block;
+    if (i1 > HW) i1 = HW;
+    if (VEC) {
+        for (int i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kThreads) {
+            float4 g = *reinterpret_cast<const float4*>(dyr + i);
+            const float4 xv = *reinterpret_cast<const float4*>(xr + i);
+            if (RELU) {
+                const float4 yv = *reinterpret_cast<const float4*>(yr + i);
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            float4 o;
+            o.x = (g.x - mean_dy - (xv.x - mu) * k) * gi;
+            o.y = (g.y - mean_dy - (xv.y - mu) * k) * gi;
+            o.z = (g.z - mean_dy - (xv.z - mu) * k) * gi;
+            o.w = (g.w - mean_dy - (xv.w - mu) * k) * gi;
+            *reinterpret_cast<float4*>(dxr + i) = o;
+            if (drr) *reinterpret_cast<float4*>(drr + i) = g;
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += kThreads) {
+            float g = dyr[i];
+            if (RELU) g = yr[i] > 0.f ? g : 0.f;
+            dxr[i] = (g - mean_dy - (xr[i] - mu) * k) * gi;
+            if (drr) drr[i] = g;
+        }
+    }
+}
+
+constexpr int kColsPerBlock = 4096;
+
+}  // namespace
+
+extern "C" size_t dcfp_bn_workspace_bytes(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    const BnPlan p = bn_plan(N, C, HW);
+    return (size_t)C * p.chunks * 2 * sizeof(float);
+}
+
+extern "C" int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C, int HW,
+                                 float* mean, float* var, void* workspace,
+                                 size_t workspace_bytes, dcfp_stream_t stream) {
+    if (!x || !mean || !var || N <= 0 || C <= 0 || HW <= 0) return DCFP_E_BADDESC;
+    if (x_nstride == 0) x_nstride = (int64_t)C * HW;
+    const BnPlan p = bn_plan(N, C, HW);
+    if (!workspace || workspace_bytes < (size_t)C * p.chunks * 2 * sizeof(float))
+        return DCFP_E_WORKSPACE;
+    float* part = static_cast<float*>(workspace);
+    const long long E = (long long)N * HW;
+    const bool vec = (HW % 4 == 0) && (x_nstride % 4 == 0) && dcfp_aligned16(x);
+    dim3 grid(p.chunks, C);
+    if (vec)
+        hipLaunchKernelGGL(bn_stats_partial_kernel<true>, grid, dim3(kThreads), 0, dcfp_s(stream), x,
+                           (long long)x_nstride, HW, E, p.chunk_elems, p.chunks, part);
+    else
+        hipLaunchKernelGGL(bn_stats_partial_kernel<false>, grid, dim3(kThreads), 0, dcfp_s(stream),
+                           x, (long long)x_nstride, HW, E, p.chunk_elems, p.chunks, part);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream),
+                       x, HW, E, C, p.chunks, part, mean, var);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps,
+                                 const float* residual, int relu, float* y, int64_t y_nstride,
+                                 int N, int C, int HW, dcfp_stream_t stream) {
+    if (!x || !mean || !var || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0)
+        return DCFP_E_BADDESC;
+    if (y_nstride == 0) y_nstride = (int64_t)C * HW;
+    const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
+    const long long blocks = (long long)N * C * colchunks;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    const bool vec = (HW % 4 == 0) && (y_nstride % 4 == 0) && dcfp_aligned16(x) &&
+                     dcfp_aligned16(y) && (!residual || dcfp_aligned16(residual));
+    if (vec)
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), x, mean, var, gamma, beta, eps, residual, relu, y,
+                           (long long)y_nstride, C, HW, colchunks, kColsPerBlock);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), x, mean, var, gamma, beta, eps, residual, relu, y,
+                           (long long)y_nstride, C, HW, colchunks, kColsPerBlock);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
+                                      const float* y, int64_t y_nstride, const float* mean,
+                                      int relu, int N, int C, int HW, float* sum_dy,
+                                      float* sum_dy_xmu, void* workspace, size_t workspace_bytes,
+                                      dcfp_stream_t stream) {
+    if (!dy || !x || !mean || !sum_dy || !sum_dy_xmu || N <= 0 || C <= 0 || HW <= 0)
+        return DCFP_E_BADDESC;
+    if (relu && !y) return DCFP_E_BADDESC;
+    if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
+    if (y_nstride == 0) y_nstride = (int64_t)C * HW;
+    const BnPlan p = bn_plan(N, C, HW);
+    if (!workspace || workspace_bytes < (size_t)C * p.chunks * 2 * sizeof(float))
+        return DCFP_E_WORKSPACE;
+    float* part = static_cast<float*>(workspace);
+    const long long E = (long long)N * HW;
+    const bool vec = (HW % 4 == 0) && (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
+                     dcfp_aligned16(dy) && dcfp_aligned16(x) && (!relu || dcfp_aligned16(y));
+    dim3 grid(p.chunks, C);
+#define LAUNCH_RED(V, R)                                                                          \
+    hipLaunchKernelGGL((bn_bwd_reduce_partial_kernel<V, R>), grid, dim3(kThreads), 0,             \
+                       dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
+                       mean, C, HW, E, p.chunk_elems, p.chunks, part)
+    if (vec) { if (relu) LAUNCH_RED(true, true); else LAUNCH_RED(true, false); }
+    else     { if (relu) LAUNCH_RED(false, true); else LAUNCH_RED(false, false); }
+#undef LAUNCH_RED
+    hipLaunchKernelGGL(bn_pair_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C,
+                       p.chunks, part, sum_dy, sum_dy_xmu);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
+                                     const float* y, int64_t y_nstride, const float* mean,
+                                     const float* var, const float* gamma, float eps,
+                                     const float* sum_dy, const float* sum_dy_xmu, float count,
+                                     int relu, float* dx, float* d_residual, int N, int C,
+                                     int HW, dcfp_stream_t stream) {
+    if (!dy || !x || !mean || !var || !gamma || !sum_dy || !sum_dy_xmu || !dx || N <= 0 ||
+        C <= 0 || HW <= 0 || !(count > 0.f))
+        return DCFP_E_BADDESC;
+    if (relu && !y) return DCFP_E_BADDESC;
+    if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
+    if (y_nstride == 0) y_nstride = (int64_t)C * HW;
+    const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
+    const long long blocks = (long long)N * C * colchunks;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    const bool vec = (HW % 4 == 0) && (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
+                     dcfp_aligned16(dy) && dcfp_aligned16(x) && dcfp_aligned16(dx) &&
+                     (!relu || dcfp_aligned16(y)) && (!d_residual || dcfp_aligned16(d_residual));
+    const float inv_count = 1.0f / count;
+#define LAUNCH_APP(V, R)                                                                          \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R>), dim3((unsigned)blocks), dim3(kThreads), 0,    \
+                       dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
+                       mean, var, gamma, eps, sum_dy, sum_dy_xmu, inv_count, dx, d_residual, C,   \
+                       HW, colchunks, kColsPerBlock)
+    if (vec) { if (relu) LAUNCH_APP(true, true); else LAUNCH_APP(true, false); }
+    else     { if (relu) LAUNCH_APP(false, true); else LAUNCH_APP(false, false); }
+#undef LAUNCH_APP
+    DCFP_RETURN_LAUNCH();
+}

@@ -1,0 +1,37 @@
+// common.h — shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dcfp_hip.h"
+
+#define DCFP_WAVE 64
+
+// launch check: a kernel launch reports configuration errors through hipGetLastError.
+#define DCFP_RETURN_LAUNCH()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        return (e__ == hipSuccess) ? DCFP_OK : (int)e__; \
+    } while (0)
+
+static inline hipStream_t dcfp_s(dcfp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool dcfp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread block in a fixed (deterministic) order; result valid in thread 0.
+__device__ __forceinline__ float block_sum_256(float v, float* smem /* >= 4 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    __syncthreads();
+    return r;
+}

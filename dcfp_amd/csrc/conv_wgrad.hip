@@ -1,0 +1,390 @@
+// conv_wgrad.hip — conv2d weight gradient on the fp32 matrix cores of gfx950.
+// Replaces the wgrad half of autograd's convolution_backward for every nn.Conv2d on
+// the hot path (networks/backbone/resnet.py:25-30,88-96; networks/tools/aspp.py:13-14;
+// networks/deeplabv3.py:25-33,37-41).
+//
+//   dW[m][n] = sum_{img, p} dY[img][m][p] * X[img][ci][src(p, tap)]     m = co, n = ci*T + tap
+// A GEMM with tiny M x N (e.g. 256 x 2304) and a huge reduction (K = N*Hout*Wout =
+// 131072 pixels at 4x128x256): the K range is split across workgroups, each split
+// writes its fp32 partial slab, and a second kernel sums the slabs in a FIXED order —
+// no float atomics, so BN-gamma / weight gradients are run-to-run reproducible
+// (SURVEY.md §7 hard parts: jitter would flip masks near the threshold).
+//
+// Both operands are pixel-contiguous in NCHW, so LDS keeps them K-contiguous:
+// As[m][k], Bs[n][k] (row pitch 20 floats: conflict-free ds_read_b128), and one
+// 16-byte read per lane feeds FOUR consecutive k-steps of a 32x32x2 MFMA tile.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;   // pixels per K-step
+constexpr int BKP = 20;  // LDS row pitch (floats)
+
+struct WgradParams {
+    const float* dy;
+    const float* x;
+    float* out;  // dw (splits == 1) or workspace slabs [splits][M][Nn]
+    long long dy_nstride, x_nstride;
+    int N, M, Cin, Nn;
+    int H, W, Ho, Wo, P, stride, pad, dil;
+    long long Kpix;
+    int kchunk, splits, tiles_m, tiles_n;
+    int quad_ok;  // Wo % 4 == 0: the 4 pixels of a quad share (img, oh)
+    int vec_dy;   // 16-byte loads of dy allowed
+};
+
+constexpr unsigned kOob = 0x80000000u;      // > any record count: buffer loads return 0
+constexpr unsigned kMaxRecords = 0x7ffffffcu;
+
+template <int TAPS, int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    constexpr int ROWS = NT / 4;  // rows staged per pass (4 threads x 4 pixels per row)
+    constexpr int PA = BM / ROWS, PB = BN / ROWS;
+    static_assert(PA >= 1 && PB >= 1 && PA * ROWS == BM && PB * ROWS == BN, "loader shape");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [2][BM][BKP]
+    float* Bs = smem + 2 * BM * BKP;      // [2][BN][BKP]
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / tiles;
+    const int tile = blockIdx.x - split * tiles;
+    const int mt = tile / p.tiles_n, ntile = tile - mt * p.tiles_n;
+    const int m0 = mt * BM, n0 = ntile * BN;
+    const long long kbeg = (long long)split * p.kchunk;
+    long long kend = kbeg + p.kchunk;
+    if (kend > p.Kpix) kend = p.Kpix;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int kx = tid & 3, rrow = tid >> 2;
+
+    // Buffer descriptors based at the first image this split touches (block-uniform);
+    // invalid lanes use offset kOob and read 0 without branching.
+    const int img0 = (int)(kbeg / p.P);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy + (long long)img0 * p.dy_nstride), 0, kMaxRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (long long)img0 * p.x_nstride), 0, kMaxRecords, 0x00020000);
+    const int dyn = (int)p.dy_nstride, xn = (int)p.x_nstride;
+
+    // ---- per-thread rows (fixed over the K loop)
+    int a_off[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int m = m0 + rrow + ROWS * j;
+        a_ok[j] = m < p.M;
+        a_off[j] = m * p.P;
+    }
+    int b_coff[PB], b_dh[PB], b_dw[PB];
+    bool b_ok[PB];
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int nn = n0 + rrow + ROWS * j;
+        b_ok[j] = nn < p.Nn;
+        const int ci = nn / TAPS;
+        const int t = nn - ci * TAPS;
+        const int kh = (TAPS == 9) ? t / 3 : 0;
+        const int kw = (TAPS == 9) ? t - kh * 3 : 0;
+        b_coff[j] = ci * HW;
+        b_dh[j] = kh * p.dil - p.pad;
+        b_dw[j] = kw * p.dil - p.pad;
+    }
+
+    float areg[PA][4], breg[PB][4];
+
+    auto load_tile = [&](long long kbase) {
+        // coordinates of this thread's 4 pixels
+        int img[4], pp[4], ih[4], iw[4];
+        bool qv[4];
+        const long long q0 = kbase + 4 * kx;
+        if (p.quad_ok) {
+            const int imabs = (int)(q0 / p.P);
+            const int pq = (int)(q0 - (long long)imabs * p.P);
+            const int im = imabs - img0;
+            const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                img[e] = im; pp[e] = pq + e;
+                ih[e] = oh * p.stride; iw[e] = (ow + e) * p.stride;
+                qv[e] = (q0 + e) < kend;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long q = q0 + e;
+                qv[e] = q < kend;
+                const int imabs = (int)(q / p.P);
+                const int pq = (int)(q - (long long)imabs * p.P);
+                const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
+                img[e] = imabs - img0; pp[e] = pq;
+                ih[e] = oh * p.stride; iw[e] = ow * p.stride;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            if (p.vec_dy) {  // block-uniform: quads are 16-byte aligned and all-or-nothing
+                const unsigned off = (a_ok[j] && qv[0])
+                                         ? (unsigned)(img[0] * dyn + a_off[j] + pp[0]) * 4u : kOob;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) areg[j][e] = __builtin_bit_cast(float, v[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned off = (a_ok[j] && qv[e])
+                                             ? (unsigned)(img[e] * dyn + a_off[j] + pp[e]) * 4u : kOob;
+                    areg[j][e] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off, 0, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hh = ih[e] + b_dh[j], ww = iw[e] + b_dw[j];
+                const bool ok = b_ok[j] && qv[e] && hh >= 0 && ww >= 0 && hh < p.H && ww < p.W;
+                const unsigned off = ok ? (unsigned)(img[e] * xn + b_coff[j] + hh * p.W + ww) * 4u : kOob;
+                breg[j][e] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, off, 0, 0));
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * (BM * BKP);
+#pragma unroll
+        for (int j = 0; j < PA; ++j)
+            *reinterpret_cast<float4*>(a + (rrow + ROWS * j) * BKP + 4 * kx) =
+                make_float4(areg[j][0], areg[j][1], areg[j][2], areg[j][3]);
+        float* b = Bs + buf * (BN * BKP);
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            *reinterpret_cast<float4*>(b + (rrow + ROWS * j) * BKP + 4 * kx) =
+                make_float4(breg[j][0], breg[j][1], breg[j][2], breg[j][3]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    if (nk > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int a_row = wm * (TM * 32) + l31;
+    const int b_row = wn * (TN * 32) + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        if (more) load_tile(kbeg + (long long)(kt + 1) * BK);
+        const float* a = As + cur * (BM * BKP) + a_row * BKP + 4 * lhi;
+        const float* b = Bs + cur * (BN * BKP) + b_row * BKP + 4 * lhi;
+#pragma unroll
+        for (int kq = 0; kq < BK / 8; ++kq) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(a + i * 32 * BKP + kq * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const float4*>(b + j * 32 * BKP + kq * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: slab [split][M][Nn] (or dw itself when splits == 1)
+    float* o = p.out + (long long)split * p.M * p.Nn;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int m = m0 + wm * (TM * 32) + i * 32 + row;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nn = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (nn < p.Nn) o[(long long)m * p.Nn + nn] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// dw[i] = sum_s slab[s][i], s ascending (fixed order).
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int splits) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (long long)gridDim.x * 256) {
+        float s = ws[i];
+        for (int k = 1; k < splits; ++k) s += ws[(long long)k * n + i];
+        dw[i] = s;
+    }
+}
+
+// db[c] = sum_{n,p} dy[n,c,p]
+__global__ void __launch_bounds__(256)
+bias_grad_kernel(const float* __restrict__ dy, long long dy_nstride, float* __restrict__ db, int N,
+                 int P) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* r = dy + (long long)n * dy_nstride + (long long)c * P;
+        for (int i = threadIdx.x; i < P; i += 256) s += r[i];
+    }
+    const float t = block_sum_256(s, red);
+    if (threadIdx.x == 0) db[c] = t;
+}
+
+struct Plan {
+    int bm, bn, cfg;  // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave)
+    int tiles_m, tiles_n, splits, kchunk;
+};
+
+Plan make_plan(const DcfpConvDesc* d) {
+    Plan pl;
+    const int M = d->Cout, Nn = d->Cin * d->KH * d->KW;
+    if (M > 128 && Nn > 128) { pl.cfg = 0; pl.bm = 256; pl.bn = 256; }
+    else if (M > 64 && Nn > 128) { pl.cfg = 1; pl.bm = 128; pl.bn = 256; }
+    else { pl.cfg = 2; pl.bm = 64; pl.bn = 64; }
+    pl.tiles_m = (M + pl.bm - 1) / pl.bm;
+    pl.tiles_n = (Nn + pl.bn - 1) / pl.bn;
+    const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
+    const long long Kpix = (long long)d->N * d->Hout * d->Wout;
+    // ~2 blocks per CU for the big tiles, ~8 for the one-wave tile; >= 8 K-steps per split
+    const long long target = pl.cfg == 2 ? 2048 : 512;
+    long long splits = (target + tiles - 1) / tiles;
+    const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long long kchunk = (Kpix + splits - 1) / splits;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    splits = (Kpix + kchunk - 1) / kchunk;
+    pl.splits = (int)splits;
+    pl.kchunk = (int)kchunk;
+    return pl;
+}
+
+int check_desc(const DcfpConvDesc* d) {
+    if (!d) return DCFP_E_BADDESC;
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->stride <= 0 ||
+        d->dil <= 0 || d->pad < 0)
+        return DCFP_E_BADDESC;
+    if (d->KH != d->KW || (d->KH != 1 && d->KH != 3)) return DCFP_E_UNSUPPORTED;
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+    if (ho != d->Hout || wo != d->Wout || ho <= 0 || wo <= 0) return DCFP_E_BADDESC;
+    if ((long long)d->Cin * d->H * d->W >= (1LL << 29) ||
+        (long long)d->Cout * d->Hout * d->Wout >= (1LL << 29) ||
+        (long long)d->Cout * d->Cin * d->KH * d->KW >= (1LL << 29))
+        return DCFP_E_UNSUPPORTED;
+    return DCFP_OK;
+}
+
+template <int TAPS, int TM, int TN, int WM, int WN>
+int launch_cfg(const WgradParams& p, long long blocks, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
+    auto kern = wgrad_kernel<TAPS, TM, TN, WM, WN>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DCFP_OK : (int)e;
+}
+
+template <int TAPS>
+int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
+    const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    switch (pl.cfg) {
+        case 0: return launch_cfg<TAPS, 4, 4, 2, 2>(p, blocks, stream);
+        case 1: return launch_cfg<TAPS, 2, 4, 2, 2>(p, blocks, stream);
+        default: return launch_cfg<TAPS, 2, 2, 1, 1>(p, blocks, stream);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
+    if (pass != DCFP_CONV_WGRAD || check_desc(d) != DCFP_OK) return 0;
+    const Plan pl = make_plan(d);
+    if (pl.splits <= 1) return 0;
+    return (size_t)pl.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
+}
+
+extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy,
+                                          int64_t dy_nstride, const float* x, float* dw, float* db,
+                                          void* workspace, size_t workspace_bytes,
+                                          dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !x || !dw) return DCFP_E_BADDESC;
+    const Plan pl = make_plan(d);
+    const int T = d->KH * d->KW;
+    const long long wn = (long long)d->Cout * d->Cin * T;
+    const size_t need = pl.splits > 1 ? (size_t)pl.splits * wn * sizeof(float) : 0;
+    if (need && (!workspace || workspace_bytes < need)) return DCFP_E_WORKSPACE;
+    WgradParams p;
+    p.dy = dy; p.x = x;
+    p.out = pl.splits > 1 ? static_cast<float*>(workspace) : dw;
+    p.dy_nstride = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout;
+    p.x_nstride = (long long)d->Cin * d->H * d->W;
+    p.N = d->N; p.M = d->Cout; p.Cin = d->Cin; p.Nn = d->Cin * T;
+    p.H = d->H; p.W = d->W; p.Ho = d->Hout; p.Wo = d->Wout; p.P = d->Hout * d->Wout;
+    p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.Kpix = (long long)d->N * p.P;
+    p.kchunk = pl.kchunk; p.splits = pl.splits; p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+    p.quad_ok = (d->Wout % 4 == 0) ? 1 : 0;
+    p.vec_dy = p.quad_ok && (p.dy_nstride % 4 == 0) && dcfp_aligned16(dy);
+    {   // 31-bit byte offsets relative to the first image of a split
+        const long long span = (long long)pl.kchunk / p.P + 2;
+        const long long big = p.dy_nstride > p.x_nstride ? p.dy_nstride : p.x_nstride;
+        if (span * big * 4 >= (1LL << 31)) return DCFP_E_UNSUPPORTED;
+    }
+    rc = T == 1 ? launch_taps<1>(p, pl, dcfp_s(stream)) : launch_taps<9>(p, pl, dcfp_s(stream));
+    if (rc) return rc;
+    if (pl.splits > 1) {
+        long long b = (wn + 255) / 256;
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(256), 0, dcfp_s(stream),
+                           static_cast<const float*>(workspace), dw, wn, pl.splits);
+    }
+    if (db) {
+        hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(256), 0, dcfp_s(stream),
+                           dy, p.dy_nstride, db, d->N, p.P);
+    }
+    DCFP_RETURN_LAUNCH();
+}

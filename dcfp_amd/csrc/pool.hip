@@ -1,0 +1,237 @@
+// pool.hip — HBM-bound element-wise / pooling kernels on the hot path:
+//   MaxPool2d(3,2,1)            networks/backbone/resnet.py:100,149
+//   AdaptiveAvgPool2d(1)        networks/tools/aspp.py:56        (dcfp_rowsum_f32)
+//   bilinear 1x1 -> HxW         networks/tools/aspp.py:76        (dcfp_broadcast_hw_f32)
+//   gradient fan-in add         autograd of resnet.py:55, aspp.py:70-77
+//   Dropout2d with host mask    networks/deeplabv3.py:40
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// One thread per output element; -inf padding; first maximum wins; NaN propagates
+// (ATen max_pool2d semantics).  argmax = h*W + w inside the input plane.
+__global__ void __launch_bounds__(kThreads)
+maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                        int32_t* __restrict__ argmax, long long total, int H, int W, int Hout,
+                        int Wout) {
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int ow = (int)(idx % Wout);
+        const long long t = idx / Wout;
+        const int oh = (int)(t % Hout);
+        const long long plane = t / Hout;
+        const float* xp = x + plane * (long long)H * W;
+        const int h0 = oh * 2 - 1, w0 = ow * 2 - 1;
+        const int hs = h0 < 0 ? 0 : h0, ws = w0 < 0 ? 0 : w0;
+        const int he = h0 + 3 > H ? H : h0 + 3, we = w0 + 3 > W ? W : w0 + 3;
+        float best = -INFINITY;
+        int bi = hs * W + ws;
+        for (int h = hs; h < he; ++h) {
+            for (int w = ws; w < we; ++w) {
+                const float v = xp[h * W + w];
+                if (v > best || v != v) {
+                    best = v;
+                    bi = h * W + w;
+                }
+            }
+        }
+        y[idx] = best;
+        argmax[idx] = bi;
+    }
+}
+
+// Gather form of the backward: every input pixel looks at the (at most 4) windows
+// that contain it — deterministic, no atomics.
+__global__ void __launch_bounds__(kThreads)
+maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ argmax,
+                        float* __restrict__ dx, long long total, int H, int W, int Hout,
+                        int Wout) {
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int w = (int)(idx % W);
+        const long long t = idx / W;
+        const int h = (int)(t % H);
+        const long long plane = t / H;
+        const float* dyp = dy + plane * (long long)Hout * Wout;
+        const int32_t* ap = argmax + plane * (long long)Hout * Wout;
+        const int me = h * W + w;
+        // windows oh with 2*oh-1 <= h <= 2*oh+1
+        const int oh_lo = h / 2, oh_hi = (h + 1) / 2;
+        const int ow_lo = w / 2, ow_hi = (w + 1) / 2;
+        float acc = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            if (oh >= Hout) continue;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                if (ow >= Wout) continue;
+                if (ap[oh * Wout + ow] == me) acc += dyp[oh * Wout + ow];
+            }
+        }
+        dx[idx] = acc;
+    }
+}
+
+// y[row] = scale * sum_i x[row, i]; one block per (n,c) row.
+__global__ void __launch_bounds__(kThreads)
+rowsum_kernel(const float* __restrict__ x, long long x_nstride, float* __restrict__ y, float scale,
+              int C, int HW, int vec) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int n = row / C, c = row - n * C;
+    const float* xr = x + (long long)n * x_nstride + (long long)c * HW;
+    float s = 0.f;
+    if (vec) {
+        for (int i = 4 * threadIdx.x; i < HW; i += 4 * kThreads) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += kThreads) s += xr[i];
+    }
+    const float t = block_sum_256(s, red);
+    if (threadIdx.x == 0) y[row] = t * scale;
+}
+
+__global__ void __launch_bounds__(kThreads)
+broadcast_hw_kernel(const float* __restrict__ v, float scale, float* __restrict__ y,
+                    long long y_nstride, int accumulate, int C, int HW, int colchunks,
+                    int cols_per_block, int vec) {
+    const int row = blockIdx.x / colchunks;
+    const int chunk = blockIdx.x - row * colchunks;
+    const int n = row / C, c = row - n * C;
+    const float val = v[row] * scale;
+    float* yr = y + (long long)n * y_nstride + (long long)c * HW;
+    const int i0 = chunk * cols_per_block;
+    int i1 = i0 + cols_per_block;
+    if (i1 > HW) i1 = HW;
+    if (vec) {
+        for (int i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kThreads) {
+            float4 o = make_float4(val, val, val, val);
+            if (accumulate) {
+                const float4 p = *reinterpret_cast<const float4*>(yr + i);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            *reinterpret_cast<float4*>(yr + i) = o;
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += kThreads) yr[i] = accumulate ? yr[i] + val : val;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+           long long n, int vec) {
+    if (vec) {
+        const long long n4 = n / 4;
+        for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4;
+             i += (long long)gridDim.x * kThreads) {
+            const float4 p = reinterpret_cast<const float4*>(a)[i];
+            const float4 q = reinterpret_cast<const float4*>(b)[i];
+            reinterpret_cast<float4*>(out)[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+        }
+        for (long long i = n4 * 4 + (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+             i += (long long)gridDim.x * kThreads)
+            out[i] = a[i] + b[i];
+    } else {
+        for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+             i += (long long)gridDim.x * kThreads)
+            out[i] = a[i] + b[i];
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+channel_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                     float* __restrict__ y, int HW, int colchunks, int cols_per_block, int vec) {
+    const int row = blockIdx.x / colchunks;
+    const int chunk = blockIdx.x - row * colchunks;
+    const float m = mask[row];
+    const float* xr = x + (long long)row * HW;
+    float* yr = y + (long long)row * HW;
+    const int i0 = chunk * cols_per_block;
+    int i1 = i0 + cols_per_block;
+    if (i1 > HW) i1 = HW;
+    if (vec) {
+        for (int i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kThreads) {
+            const float4 p = *reinterpret_cast<const float4*>(xr + i);
+            *reinterpret_cast<float4*>(yr + i) = make_float4(p.x * m, p.y * m, p.z * m, p.w * m);
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += kThreads) yr[i] = xr[i] * m;
+    }
+}
+
+constexpr int kCols = 4096;
+inline unsigned stream_grid(long long total) {
+    long long b = (total + kThreads - 1) / kThreads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int dcfp_maxpool3x3s2_fwd_f32(const float* x, float* y, int32_t* argmax, int N, int C,
+                                         int H, int W, int Hout, int Wout, dcfp_stream_t stream) {
+    if (!x || !y || !argmax || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
+    if (Hout != (H + 2 - 3) / 2 + 1 || Wout != (W + 2 - 3) / 2 + 1) return DCFP_E_BADDESC;
+    if ((long long)H * W > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    const long long total = (long long)N * C * Hout * Wout;
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(stream_grid(total)), dim3(kThreads), 0,
+                       dcfp_s(stream), x, y, argmax, total, H, W, Hout, Wout);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_maxpool3x3s2_bwd_f32(const float* dy, const int32_t* argmax, float* dx, int N,
+                                         int C, int H, int W, int Hout, int Wout,
+                                         dcfp_stream_t stream) {
+    if (!dy || !dx || !argmax || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
+    if (Hout != (H + 2 - 3) / 2 + 1 || Wout != (W + 2 - 3) / 2 + 1) return DCFP_E_BADDESC;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(stream_grid(total)), dim3(kThreads), 0,
+                       dcfp_s(stream), dy, argmax, dx, total, H, W, Hout, Wout);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_rowsum_f32(const float* x, int64_t x_nstride, float* y, float scale, int N,
+                               int C, int HW, dcfp_stream_t stream) {
+    if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return DCFP_E_BADDESC;
+    if (x_nstride == 0) x_nstride = (int64_t)C * HW;
+    const int vec = (HW % 4 == 0) && (x_nstride % 4 == 0) && dcfp_aligned16(x);
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)(N * C)), dim3(kThreads), 0, dcfp_s(stream), x,
+                       (long long)x_nstride, y, scale, C, HW, vec);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_broadcast_hw_f32(const float* v, float scale, float* y, int64_t y_nstride,
+                                     int accumulate, int N, int C, int HW, dcfp_stream_t stream) {
+    if (!v || !y || N <= 0 || C <= 0 || HW <= 0) return DCFP_E_BADDESC;
+    if (y_nstride == 0) y_nstride = (int64_t)C * HW;
+    const int colchunks = (HW + kCols - 1) / kCols;
+    const int vec = (HW % 4 == 0) && (y_nstride % 4 == 0) && dcfp_aligned16(y);
+    hipLaunchKernelGGL(broadcast_hw_kernel, dim3((unsigned)(N * C * colchunks)), dim3(kThreads), 0,
+                       dcfp_s(stream), v, scale, y, (long long)y_nstride, accumulate, C, HW,
+                       colchunks, kCols, vec);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_add_f32(const float* a, const float* b, float* out, int64_t n,
+                            dcfp_stream_t stream) {
+    if (!a || !b || !out || n < 0) return DCFP_E_BADDESC;
+    if (n == 0) return DCFP_OK;
+    const int vec = dcfp_aligned16(a) && dcfp_aligned16(b) && dcfp_aligned16(out);
+    hipLaunchKernelGGL(add_kernel, dim3(stream_grid((n + 3) / 4)), dim3(kThreads), 0, dcfp_s(stream),
+                       a, b, out, (long long)n, vec);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_channel_scale_f32(const float* x, const float* mask, float* y, int N, int C,
+                                      int HW, dcfp_stream_t stream) {
+    if (!x || !mask || !y || N <= 0 || C <= 0 || HW <= 0) return DCFP_E_BADDESC;
+    const int colchunks = (HW + kCols - 1) / kCols;
+    const int vec = (HW % 4 == 0) && dcfp_aligned16(x) && dcfp_aligned16(y);
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((unsigned)(N * C * colchunks)), dim3(kThreads), 0,
+                       dcfp_s(stream), x, mask, y, HW, colchunks, kCols, vec);
+    DCFP_RETURN_LAUNCH();
+}

@@ -1,0 +1,336 @@
+// upsample_ce.hip — bilinear upsample (F.interpolate, networks/deeplabv3.py:47,50) and its
+// fusion with nn.CrossEntropyLoss(ignore_index, 'mean') (loss/criterion.py:60,65-67).
+//
+// The fused pair never materialises the N x C x H x W logits (637 MB per head at
+// 4x19x1024x2048): forward reads the low-resolution logits (L1/L2 resident) and the
+// labels, and keeps one float per pixel (log-sum-exp); backward GATHERS, per
+// low-resolution cell and class, the contributions of the <= ~16x16 full-resolution
+// pixels that touch that cell, so there are no float atomics and the result is
+// run-to-run deterministic.
+//
+// Coordinate rules follow ATen's area_pixel_compute_scale / _source_index:
+//   align_corners: scale = (in-1)/(out-1) (0 if out==1), src = scale*dst
+//   otherwise    : scale = in/out,        src = max(scale*(dst+0.5)-0.5, 0)
+//   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLossBlocks = 2048;
+
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+
+template <bool ALIGN>
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_size) {
+    float src;
+    if (ALIGN) {
+        src = scale * (float)dst;
+    } else {
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+    }
+    Lerp r;
+    int i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    r.i0 = i0;
+    r.i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    float l1 = src - (float)i0;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    r.l1 = l1;
+    r.l0 = 1.f - l1;
+    return r;
+}
+
+inline float host_scale(int in, int out, int align) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
+// Conservative [lo, hi] range of destination indices whose taps may include source cell i.
+template <bool ALIGN>
+__device__ __forceinline__ void dst_range(int i, float scale, int out_size, int& lo, int& hi) {
+    if (!(scale > 0.f)) {  // out_size == 1 under align_corners
+        lo = 0;
+        hi = out_size - 1;
+        return;
+    }
+    float a, b;
+    if (ALIGN) {
+        a = ((float)i - 1.f) / scale;
+        b = ((float)i + 1.f) / scale;
+    } else {
+        a = ((float)i - 0.5f) / scale - 0.5f;
+        b = ((float)i + 1.5f) / scale - 0.5f;
+    }
+    int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+    lo = l < 0 ? 0 : l;
+    hi = h > out_size - 1 ? out_size - 1 : h;
+}
+
+__device__ __forceinline__ float tap_weight(const Lerp& L, int i) {
+    return (L.i0 == i ? L.l0 : 0.f) + (L.i1 == i ? L.l1 : 0.f);
+}
+
+// ------------------------------------------------------------ plain upsample
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int h,
+                    int w, int H, int W, float sh, float sw) {
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int X = (int)(idx % W);
+        const long long t = idx / W;
+        const int Y = (int)(t % H);
+        const long long plane = t / H;
+        const Lerp Lh = lerp_of<ALIGN>(Y, sh, h), Lw = lerp_of<ALIGN>(X, sw, w);
+        const float* p = x + plane * (long long)h * w;
+        const float top = Lw.l0 * p[Lh.i0 * w + Lw.i0] + Lw.l1 * p[Lh.i0 * w + Lw.i1];
+        const float bot = Lw.l0 * p[Lh.i1 * w + Lw.i0] + Lw.l1 * p[Lh.i1 * w + Lw.i1];
+        y[idx] = Lh.l0 * top + Lh.l1 * bot;
+    }
+}
+
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long total, int h,
+                    int w, int H, int W, float sh, float sw) {
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int j = (int)(idx % w);
+        const long long t = idx / w;
+        const int i = (int)(t % h);
+        const long long plane = t / h;
+        const float* g = dy + plane * (long long)H * W;
+        int ylo, yhi, xlo, xhi;
+        dst_range<ALIGN>(i, sh, H, ylo, yhi);
+        dst_range<ALIGN>(j, sw, W, xlo, xhi);
+        float acc = 0.f;
+        for (int Y = ylo; Y <= yhi; ++Y) {
+            const float wy = tap_weight(lerp_of<ALIGN>(Y, sh, h), i);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int X = xlo; X <= xhi; ++X) {
+                const float wx = tap_weight(lerp_of<ALIGN>(X, sw, w), j);
+                if (wx != 0.f) row += wx * g[(long long)Y * W + X];
+            }
+            acc += wy * row;
+        }
+        dx[idx] = acc;
+    }
+}
+
+// ------------------------------------------------------- fused upsample + CE
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                       const uint8_t* __restrict__ keep, int ignore_index, int N, int C, int h,
+                       int w, int H, int W, float sh, float sw, float* __restrict__ lse_out,
+                       float* __restrict__ gt_prob, float* __restrict__ part) {
+    __shared__ float red[4];
+    const long long total = (long long)N * H * W;
+    const long long plane = (long long)h * w;
+    float loss = 0.f, cnt = 0.f;
+    for (long long pix = (long long)blockIdx.x * kThreads + threadIdx.x; pix < total;
+         pix += (long long)gridDim.x * kThreads) {
+        const int X = (int)(pix % W);
+        const long long t = pix / W;
+        const int Y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Lerp Lh = lerp_of<ALIGN>(Y, sh, h), Lw = lerp_of<ALIGN>(X, sw, w);
+        const int o00 = Lh.i0 * w + Lw.i0, o01 = Lh.i0 * w + Lw.i1;
+        const int o10 = Lh.i1 * w + Lw.i0, o11 = Lh.i1 * w + Lw.i1;
+        const float* base = logits + (long long)n * C * plane;
+        const long long label = labels[pix];
+        float m = -INFINITY, s = 0.f, zl = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* p = base + c * plane;
+            const float z = Lh.l0 * (Lw.l0 * p[o00] + Lw.l1 * p[o01]) +
+                            Lh.l1 * (Lw.l0 * p[o10] + Lw.l1 * p[o11]);
+            if (z > m) {
+                s = s * expf(m - z) + 1.f;
+                m = z;
+            } else {
+                s += expf(z - m);
+            }
+            if (c == label) zl = z;
+        }
+        const float lse = m + logf(s);
+        const bool labelled = label != ignore_index;
+        const bool valid = labelled && (!keep || keep[pix]);
+        if (lse_out) lse_out[pix] = lse;
+        if (gt_prob) gt_prob[pix] = labelled ? expf(zl - lse) : 1.f;
+        if (valid) {
+            loss += lse - zl;
+            cnt += 1.f;
+        }
+    }
+    const float t1 = block_sum_256(loss, red);
+    const float t2 = block_sum_256(cnt, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = t1;
+        part[blockIdx.x * 2 + 1] = t2;
+    }
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ part, int nblocks,
+                                  float* __restrict__ out2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblocks; ++k) {
+        a += (double)part[2 * k];
+        b += (double)part[2 * k + 1];
+    }
+    out2[0] = (float)a;
+    out2[1] = (float)b;
+}
+
+// thread <-> one element of dlogits[n,c,i,j]
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                       const uint8_t* __restrict__ keep, int ignore_index, int N, int C, int h,
+                       int w, int H, int W, float sh, float sw, const float* __restrict__ lse,
+                       const float* __restrict__ grad_scale, float* __restrict__ dlogits) {
+    const long long total = (long long)N * C * h * w;
+    const float gs = grad_scale[0];
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int j = (int)(idx % w);
+        long long t = idx / w;
+        const int i = (int)(t % h);
+        t /= h;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        const float* p = logits + ((long long)n * C + c) * h * w;
+        const long long* lab = labels + (long long)n * H * W;
+        const float* ls = lse + (long long)n * H * W;
+        const uint8_t* kp = keep ? keep + (long long)n * H * W : nullptr;
+        int ylo, yhi, xlo, xhi;
+        dst_range<ALIGN>(i, sh, H, ylo, yhi);
+        dst_range<ALIGN>(j, sw, W, xlo, xhi);
+        float acc = 0.f;
+        for (int Y = ylo; Y <= yhi; ++Y) {
+            const Lerp Lh = lerp_of<ALIGN>(Y, sh, h);
+            const float wy = tap_weight(Lh, i);
+            if (wy == 0.f) continue;
+            const float* r0 = p + Lh.i0 * w;
+            const float* r1 = p + Lh.i1 * w;
+            float row = 0.f;
+            for (int X = xlo; X <= xhi; ++X) {
+                const Lerp Lw = lerp_of<ALIGN>(X, sw, w);
+                const float wx = tap_weight(Lw, j);
+                if (wx == 0.f) continue;
+                const long long q = (long long)Y * W + X;
+                const long long label = lab[q];
+                if (label == ignore_index || (kp && !kp[q])) continue;
+                const float z = Lh.l0 * (Lw.l0 * r0[Lw.i0] + Lw.l1 * r0[Lw.i1]) +
+                                Lh.l1 * (Lw.l0 * r1[Lw.i0] + Lw.l1 * r1[Lw.i1]);
+                const float prob = expf(z - ls[q]);
+                row += wx * (prob - (label == c ? 1.f : 0.f));
+            }
+            acc += wy * row;
+        }
+        dlogits[idx] = acc * gs;
+    }
+}
+
+inline unsigned stream_grid(long long total) {
+    long long b = (total + kThreads - 1) / kThreads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int dcfp_upsample_bilinear_fwd_f32(const float* x, float* y, int N, int C, int h, int w,
+                                              int H, int W, int align_corners,
+                                              dcfp_stream_t stream) {
+    if (!x || !y || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
+    const long long total = (long long)N * C * H * W;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_fwd_kernel<true>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), x, y, total, h, w, H, W, sh, sw);
+    else
+        hipLaunchKernelGGL(upsample_fwd_kernel<false>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), x, y, total, h, w, H, W, sh, sw);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_upsample_bilinear_bwd_f32(const float* dy, float* dx, int N, int C, int h,
+                                              int w, int H, int W, int align_corners,
+                                              dcfp_stream_t stream) {
+    if (!dy || !dx || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
+    const long long total = (long long)N * C * h * w;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_bwd_kernel<true>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), dy, dx, total, h, w, H, W, sh, sw);
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel<false>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), dy, dx, total, h, w, H, W, sh, sw);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" size_t dcfp_upsample_ce_workspace_bytes(int N, int H, int W) {
+    (void)N; (void)H; (void)W;
+    return (size_t)kLossBlocks * 2 * sizeof(float);
+}
+
+extern "C" int dcfp_upsample_ce_fwd_f32(const float* logits, const int64_t* labels,
+                                        const uint8_t* pixel_keep, int ignore_index, int N, int C,
+                                        int h, int w, int H, int W, int align_corners, float* lse,
+                                        float* gt_prob, float* out2, void* workspace,
+                                        size_t workspace_bytes, dcfp_stream_t stream) {
+    if (!logits || !labels || !out2 || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return DCFP_E_BADDESC;
+    if (!workspace || workspace_bytes < (size_t)kLossBlocks * 2 * sizeof(float))
+        return DCFP_E_WORKSPACE;
+    const long long total = (long long)N * H * W;
+    long long blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > kLossBlocks) blocks = kLossBlocks;
+    float* part = static_cast<float*>(workspace);
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    const long long* lab = reinterpret_cast<const long long*>(labels);
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_ce_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, C, h, w, H, W,
+                           sh, sw, lse, gt_prob, part);
+    else
+        hipLaunchKernelGGL(upsample_ce_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, C, h, w, H, W,
+                           sh, sw, lse, gt_prob, part);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, dcfp_s(stream), part, (int)blocks,
+                       out2);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labels,
+                                        const uint8_t* pixel_keep, int ignore_index, int N, int C,
+                                        int h, int w, int H, int W, int align_corners,
+                                        const float* lse, const float* grad_scale, float* dlogits,
+                                        dcfp_stream_t stream) {
+    if (!logits || !labels || !lse || !grad_scale || !dlogits || N <= 0 || C <= 0 || h <= 0 ||
+        w <= 0 || H <= 0 || W <= 0)
+        return DCFP_E_BADDESC;
+    const long long total = (long long)N * C * h * w;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    const long long* lab = reinterpret_cast<const long long*>(labels);
+    long long blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_ce_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, C, h, w, H, W,
+                           sh, sw, lse, grad_scale, dlogits);
+    else
+        hipLaunchKernelGGL(upsample_ce_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, C, h, w, H, W,
+                           sh, sw, lse, grad_scale, dlogits);
+    DCFP_RETURN_LAUNCH();
+}

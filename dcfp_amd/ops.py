@@ -1,0 +1,478 @@
+"""Tensor-level wrappers and autograd Functions over the C-ABI (include/dcfp_hip.h).
+
+PyTorch supplies device memory, streams and autograd bookkeeping; every FLOP and byte
+moved on the hot path below happens in libdcfp_hip.so.  Inputs must be CUDA (HIP) fp32
+tensors — there is deliberately no CPU / eager fallback.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+_ws_cache = {}
+
+
+def _require(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"dcfp_amd: {name} must be a CUDA/HIP tensor (no CPU fallback exists)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"dcfp_amd: {name} must be float32, got {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _workspace(tag, nbytes, device):
+    """Grow-only scratch per (tag, device); reuse is safe because launches are stream-ordered."""
+    key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _batch_strided(t):
+    """Return (tensor, batch_stride) for a [N,C,H,W] tensor whose images are dense
+    (a channel slice of a wider tensor qualifies); otherwise a contiguous copy."""
+    N, Cc, H, W = t.shape
+    st = t.stride()
+    if st[3] == 1 and st[2] == W and st[1] == H * W and (N == 1 or st[0] >= Cc * H * W):
+        return t, (st[0] if N > 1 else Cc * H * W)
+    t = t.contiguous()
+    return t, Cc * H * W
+
+
+def conv_out_size(size, k, stride, pad, dil):
+    return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _desc(xshape, wshape, stride, pad, dil):
+    N, Cin, H, W = xshape
+    Cout, Cin2, KH, KW = wshape
+    if Cin2 != Cin:
+        raise RuntimeError(f"conv2d: weight expects {Cin2} input channels, got {Cin} (groups unsupported)")
+    d = ConvDesc(N, Cin, H, W, Cout, KH, KW, stride, pad, dil,
+                 conv_out_size(H, KH, stride, pad, dil), conv_out_size(W, KW, stride, pad, dil))
+    return d
+
+
+# ------------------------------------------------------------------ conv2d
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1):
+    _require(x, "x"); _require(w, "weight")
+    x = x.contiguous(); w = w.contiguous()
+    d = _desc(x.shape, w.shape, stride, pad, dil)
+    y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        _require(bias, "bias"); bias = bias.contiguous()
+    check(_lib.lib().dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), 0, _stream()),
+          "conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(dy, w, xshape, stride, pad, dil):
+    _require(dy, "dy")
+    w = w.contiguous()
+    d = _desc(xshape, w.shape, stride, pad, dil)
+    dy, ns = _batch_strided(dy)
+    dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), 0, _stream()),
+          "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False):
+    _require(dy, "dy"); _require(x, "x")
+    x = x.contiguous()
+    d = _desc(x.shape, wshape, stride, pad, dil)
+    dy, ns = _batch_strided(dy)
+    L = _lib.lib()
+    nbytes = L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_WGRAD)
+    ws = _workspace("wgrad", nbytes, x.device)
+    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+    db = torch.empty((wshape[0],), dtype=torch.float32, device=x.device) if need_bias else None
+    check(L.dcfp_conv2d_wgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(x), _p(dw), _p(db), _p(ws),
+                                       ws.numel(), _stream()), "conv2d_wgrad")
+    return dw, db
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward (reference: every conv in networks/backbone/resnet.py,
+    networks/tools/aspp.py, networks/deeplabv3.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        y = conv2d_fwd(x, w, bias, stride, pad, dil)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.cfg
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(dy, w, tuple(x.shape), stride, pad, dil)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, dil, need_bias=has_bias)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil)
+
+
+# ------------------------------------------------------------- batch norm
+def bn_stats(x):
+    _require(x, "x")
+    N, Cc, H, W = x.shape
+    x, ns = _batch_strided(x)
+    L = _lib.lib()
+    ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    var = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    check(L.dcfp_bn_stats_f32(_p(x), ns, N, Cc, H * W, _p(mean), _p(var), _p(ws), ws.numel(), _stream()),
+          "bn_stats")
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
+    N, Cc, H, W = x.shape
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().dcfp_bn_apply_f32(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps),
+                                       _p(residual), int(relu), _p(y), 0, N, Cc, H * W, _stream()),
+          "bn_apply")
+    return y
+
+
+def bn_bwd_reduce(dy, x, y, mean, relu):
+    N, Cc, H, W = x.shape
+    dy, dns = _batch_strided(dy)
+    L = _lib.lib()
+    ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
+    s1 = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    s2 = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    check(L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean), int(relu),
+                                   N, Cc, H * W, _p(s1), _p(s2), _p(ws), ws.numel(), _stream()),
+          "bn_bwd_reduce")
+    return s1, s2
+
+
+def bn_bwd_apply(dy, x, y, mean, var, gamma, eps, s1, s2, count, relu, want_residual):
+    N, Cc, H, W = x.shape
+    dy, dns = _batch_strided(dy)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_residual else None
+    check(_lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean),
+                                           _p(var), _p(gamma), float(eps), _p(s1), _p(s2), float(count),
+                                           int(relu), _p(dx), _p(dres), N, Cc, H * W, _stream()),
+          "bn_bwd_apply")
+    return dx, dres
+
+
+def _sync_group(group):
+    if group is False or not dist.is_available() or not dist.is_initialized():
+        return None
+    g = None if group is True else group
+    if dist.get_world_size(g) <= 1:
+        return None
+    return g if g is not None else dist.group.WORLD
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """y = act(BN(x) [+ residual]) with batch statistics (training) or running statistics
+    (eval).  Mirrors nn.BatchNorm2d + nn.ReLU(inplace) (+ the Bottleneck residual add,
+    networks/backbone/resnet.py:41-56); `sync` reproduces nn.SyncBatchNorm (engine.py:65):
+    statistics pooled over all ranks, gamma/beta gradients left local for the gradient
+    all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, training,
+                momentum, eps, sync):
+        _require(x, "x")
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        count = float(N * H * W)
+        group = _sync_group(sync) if training else None
+        if training:
+            mean, var = bn_stats(x)
+            if group is not None:
+                # all_gather of [mean, var, count] (2C+1 floats), Chan-combined on every rank
+                world = dist.get_world_size(group)
+                local = torch.cat([mean, var, torch.tensor([count], device=x.device)])
+                allv = torch.empty(world, local.numel(), device=x.device)
+                dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group)
+                means, vars_, counts = allv[:, :Cc], allv[:, Cc:2 * Cc], allv[:, 2 * Cc:]
+                total = counts.sum()
+                gmean = (means * counts).sum(0) / total
+                gvar = ((vars_ + (means - gmean) ** 2) * counts).sum(0) / total
+                mean, var, count = gmean.contiguous(), gvar.contiguous(), float(total.item())
+            if running_mean is not None and momentum is not None:
+                with torch.no_grad():
+                    unbiased = var * (count / max(count - 1.0, 1.0))
+                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
+        else:
+            mean, var = running_mean, running_var
+        y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
+        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
+        ctx.cfg = (relu, training, eps, count, group, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        relu, training, eps, count, group, has_res = ctx.cfg
+        s1, s2 = bn_bwd_reduce(dy, x, y, mean, relu)
+        istd = torch.rsqrt(var + eps)
+        dgamma = s2 * istd
+        dbeta = s1
+        if training:
+            if group is not None:
+                both = torch.cat([s1, s2])
+                dist.all_reduce(both, group=group)
+                Cc = s1.numel()
+                r1, r2 = both[:Cc].contiguous(), both[Cc:].contiguous()
+            else:
+                r1, r2 = s1, s2
+        else:  # running statistics are constants: dx = g * gamma * istd
+            r1 = torch.zeros_like(s1); r2 = torch.zeros_like(s2)
+        need_res = has_res and ctx.needs_input_grad[5]
+        dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, eps, r1, r2, count, relu, need_res)
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
+                   training=True, momentum=0.1, eps=1e-5, sync=False):
+    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, relu,
+                                training, momentum, eps, sync)
+
+
+# ---------------------------------------------------------------- pooling
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (networks/backbone/resnet.py:100)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "x")
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, Cc, Ho, Wo), dtype=torch.int32, device=x.device)
+        check(_lib.lib().dcfp_maxpool3x3s2_fwd_f32(_p(x), _p(y), _p(idx), N, Cc, H, W, Ho, Wo, _stream()),
+              "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, Cc, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, Cc, H, W, Ho, Wo = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dy.device)
+        check(_lib.lib().dcfp_maxpool3x3s2_bwd_f32(_p(dy), _p(idx), _p(dx), N, Cc, H, W, Ho, Wo, _stream()),
+              "maxpool_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    return MaxPool3x3s2Fn.apply(x)
+
+
+def rowsum(x, scale):
+    N, Cc, H, W = x.shape
+    x, ns = _batch_strided(x)
+    y = torch.empty((N, Cc, 1, 1), dtype=torch.float32, device=x.device)
+    check(_lib.lib().dcfp_rowsum_f32(_p(x), ns, _p(y), float(scale), N, Cc, H * W, _stream()), "rowsum")
+    return y
+
+
+def broadcast_hw(v, H, W, scale=1.0):
+    N, Cc = v.shape[0], v.shape[1]
+    v = v.contiguous()
+    y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=v.device)
+    check(_lib.lib().dcfp_broadcast_hw_f32(_p(v), float(scale), _p(y), 0, 0, N, Cc, H * W, _stream()),
+          "broadcast_hw")
+    return y
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) (networks/tools/aspp.py:56)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "x")
+        ctx.hw = (x.shape[2], x.shape[3])
+        return rowsum(x, 1.0 / (x.shape[2] * x.shape[3]))
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W = ctx.hw
+        return broadcast_hw(dy, H, W, 1.0 / (H * W))
+
+
+class BroadcastHWFn(torch.autograd.Function):
+    """F.interpolate of a 1x1 map to HxW (networks/tools/aspp.py:76): a constant broadcast
+    for either align_corners setting."""
+
+    @staticmethod
+    def forward(ctx, v, H, W):
+        _require(v, "v")
+        return broadcast_hw(v, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return rowsum(dy, 1.0), None, None
+
+
+def global_avg_pool(x):
+    return GlobalAvgPoolFn.apply(x)
+
+
+def broadcast_to_hw(v, H, W):
+    return BroadcastHWFn.apply(v, H, W)
+
+
+class ChannelScaleFn(torch.autograd.Function):
+    """nn.Dropout2d with a host-drawn per-(n,c) keep/scale mask (networks/deeplabv3.py:40)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        _require(x, "x")
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        mask = mask.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.lib().dcfp_channel_scale_f32(_p(x), _p(mask), _p(y), N, Cc, H * W, _stream()),
+              "channel_scale")
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Cc, H, W = dy.shape
+        dx = torch.empty_like(dy)
+        check(_lib.lib().dcfp_channel_scale_f32(_p(dy), _p(mask), _p(dx), N, Cc, H * W, _stream()),
+              "channel_scale")
+        return dx, None
+
+
+def dropout2d(x, p, training, fixed_mask=None):
+    if not training or p == 0.0:
+        return x
+    if fixed_mask is not None:
+        mask = fixed_mask.to(device=x.device, dtype=torch.float32)
+    else:
+        mask = torch.empty(x.shape[0], x.shape[1], device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)
+    return ChannelScaleFn.apply(x, mask)
+
+
+def add(a, b):
+    """out = a + b through the library (gradient fan-in)."""
+    a = a.contiguous(); b = b.contiguous()
+    out = torch.empty_like(a)
+    check(_lib.lib().dcfp_add_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "add")
+    return out
+
+
+# --------------------------------------------- bilinear upsample (+) cross-entropy
+class UpsampleBilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners) (networks/deeplabv3.py:47,50)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, align_corners):
+        _require(x, "x")
+        x = x.contiguous()
+        N, Cc, h, w = x.shape
+        y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+        check(_lib.lib().dcfp_upsample_bilinear_fwd_f32(_p(x), _p(y), N, Cc, h, w, H, W,
+                                                        int(bool(align_corners)), _stream()),
+              "upsample_fwd")
+        ctx.cfg = (N, Cc, h, w, H, W, int(bool(align_corners)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, h, w, H, W, ac = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((N, Cc, h, w), dtype=torch.float32, device=dy.device)
+        check(_lib.lib().dcfp_upsample_bilinear_bwd_f32(_p(dy), _p(dx), N, Cc, h, w, H, W, ac, _stream()),
+              "upsample_bwd")
+        return dx, None, None, None
+
+
+def upsample_bilinear(x, size, align_corners):
+    return UpsampleBilinearFn.apply(x, int(size[0]), int(size[1]), align_corners)
+
+
+def upsample_ce_forward(logits, labels, size, align_corners, ignore_index, pixel_keep=None,
+                        want_gt_prob=False):
+    """Returns (out2=[loss_sum, valid_count], lse[N,H,W], gt_prob or None)."""
+    _require(logits, "logits")
+    logits = logits.contiguous()
+    if labels.dtype != torch.int64 or not labels.is_cuda:
+        raise RuntimeError("upsample_ce: labels must be a CUDA int64 tensor [N,H,W]")
+    labels = labels.contiguous()
+    N, Cc, h, w = logits.shape
+    H, W = int(size[0]), int(size[1])
+    if tuple(labels.shape) != (N, H, W):
+        raise RuntimeError(f"upsample_ce: labels shape {tuple(labels.shape)} != {(N, H, W)}")
+    L = _lib.lib()
+    ws = _workspace("ce", L.dcfp_upsample_ce_workspace_bytes(N, H, W), logits.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    lse = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
+    gtp = torch.empty((N, H, W), dtype=torch.float32, device=logits.device) if want_gt_prob else None
+    if pixel_keep is not None:
+        pixel_keep = pixel_keep.to(torch.uint8).contiguous()
+    check(L.dcfp_upsample_ce_fwd_f32(_p(logits), _p(labels), _p(pixel_keep), int(ignore_index), N, Cc,
+                                     h, w, H, W, int(bool(align_corners)), _p(lse), _p(gtp), _p(out2),
+                                     _p(ws), ws.numel(), _stream()), "upsample_ce_fwd")
+    return out2, lse, gtp
+
+
+class UpsampleCEFn(torch.autograd.Function):
+    """loss = CrossEntropyLoss(ignore_index, 'mean')(F.interpolate(logits, size), labels),
+    fused (networks/deeplabv3.py:47,50 + loss/criterion.py:60)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, H, W, align_corners, ignore_index, pixel_keep):
+        out2, lse, _ = upsample_ce_forward(logits, labels, (H, W), align_corners, ignore_index, pixel_keep)
+        ctx.save_for_backward(logits, labels, lse, out2, pixel_keep)
+        ctx.cfg = (H, W, int(bool(align_corners)), int(ignore_index))
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, lse, out2, pixel_keep = ctx.saved_tensors
+        H, W, ac, ignore = ctx.cfg
+        logits = logits.contiguous()
+        N, Cc, h, w = logits.shape
+        scale = (gout / out2[1]).reshape(1).to(torch.float32).contiguous()
+        dl = torch.empty_like(logits)
+        check(_lib.lib().dcfp_upsample_ce_bwd_f32(_p(logits), _p(labels.contiguous()), _p(pixel_keep),
+                                                  ignore, N, Cc, h, w, H, W, ac, _p(lse), _p(scale),
+                                                  _p(dl), _stream()), "upsample_ce_bwd")
+        return dl, None, None, None, None, None, None
+
+
+def upsample_cross_entropy(logits, labels, size, align_corners, ignore_index=255, pixel_keep=None):
+    if pixel_keep is not None:
+        pixel_keep = pixel_keep.to(torch.uint8).contiguous()
+    return UpsampleCEFn.apply(logits, labels, int(size[0]), int(size[1]), align_corners,
+                              ignore_index, pixel_keep)

@@ -1,0 +1,200 @@
+/*
+ * dcfp_hip.h — C-ABI of libdcfp_hip.so: the MI355X (gfx950) kernels under the DCFP
+ * segmentation-training hot path.
+ *
+ * The reference (wzx99/DCFP) has no native ABI: every op below is reached through a
+ * stock torch.nn module (cuDNN / ATen).  Each entry point cites the reference call
+ * site it replaces (file:line into the reference tree) — SURVEY.md §8(a)/(b).
+ *
+ * Conventions
+ *   - every buffer (including workspace) is owned by the caller; the library
+ *     allocates nothing and keeps no mutable global state; all launches are
+ *     stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - tensors are fp32, NCHW, dense unless a *_nstride (batch stride, in elements)
+ *     argument says otherwise.
+ *   - return value: 0 ok; <0 bad descriptor / unsupported shape (DCFP_E_*);
+ *     >0 a hipError_t from the launch.  Nothing throws across the ABI.
+ */
+#ifndef DCFP_HIP_H
+#define DCFP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCFP_OK 0
+#define DCFP_E_BADDESC (-1)     /* inconsistent sizes / null pointer            */
+#define DCFP_E_UNSUPPORTED (-2) /* kernel size other than 1x1 / 3x3, groups...  */
+#define DCFP_E_WORKSPACE (-3)   /* workspace too small                          */
+
+typedef void* dcfp_stream_t; /* hipStream_t */
+
+/* ABI version of this header (bumped on any signature change). */
+int dcfp_abi_version(void);
+
+/* ------------------------------------------------------------------ conv2d
+ * Replaces nn.Conv2d fwd + autograd dgrad/wgrad:
+ *   networks/backbone/resnet.py:25-30 (Bottleneck), :88-96 (deep stem),
+ *   :110-114,127-131 (downsample), networks/tools/aspp.py:13-14,57,63,
+ *   networks/deeplabv3.py:25-33,37-41 (heads).
+ * Cross-correlation, zero padding, groups=1, square kernel 1x1 or 3x3.
+ * Hout = (H + 2*pad - dil*(K-1) - 1)/stride + 1 must match the descriptor.
+ */
+typedef struct DcfpConvDesc {
+    int32_t N, Cin, H, W;       /* input  [N,Cin,H,W]                  */
+    int32_t Cout, KH, KW;       /* weight [Cout,Cin,KH,KW]             */
+    int32_t stride, pad, dil;   /* same in h and w                     */
+    int32_t Hout, Wout;         /* output [N,Cout,Hout,Wout]           */
+} DcfpConvDesc;
+
+enum { DCFP_CONV_FWD = 0, DCFP_CONV_DGRAD = 1, DCFP_CONV_WGRAD = 2 };
+
+/* Bytes of workspace a pass needs (0 for fwd/dgrad; split-K slabs for wgrad). */
+size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass);
+
+/* y = conv(x, w) (+ bias[co] when bias != NULL).  y_nstride: batch stride of y in
+ * elements (0 => Cout*Hout*Wout), lets a branch write into a channel slice of a
+ * wider tensor (ASPP concat, aspp.py:77). */
+int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
+                             const float* bias, float* y, int64_t y_nstride,
+                             dcfp_stream_t stream);
+/* dx = conv_transpose(dy, w); accumulate != 0 => dx += (fan-out gradients).
+ * dy_nstride: batch stride of dy in elements (0 => dense). */
+int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
+                               const float* w, float* dx, int accumulate,
+                               dcfp_stream_t stream);
+/* dw[co,ci,kh,kw] = sum_{n,p} dy[n,co,p] * x[n,ci,src(p,kh,kw)]; deterministic
+ * two-stage split-K (no float atomics).  db (nullable) = sum_{n,p} dy. */
+int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
+                               const float* x, float* dw, float* db,
+                               void* workspace, size_t workspace_bytes,
+                               dcfp_stream_t stream);
+
+/* ------------------------------------------------------------- batch norm
+ * Replaces nn.BatchNorm2d(+ReLU inplace)(+residual add) train fwd/bwd:
+ *   resnet.py:9,26-33,41-56; aspp.py:15-16,22-24; deeplabv3.py:26-31,38-39.
+ * Statistics over (N,H,W) per channel; biased variance for normalisation.
+ */
+/* Per-channel batch mean and biased variance of x[N,C,HW] (x_nstride elements
+ * between images; 0 => C*HW).  workspace: dcfp_bn_workspace_bytes(N,C,HW). */
+size_t dcfp_bn_workspace_bytes(int N, int C, int HW);
+int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C, int HW,
+                      float* mean, float* var, void* workspace, size_t workspace_bytes,
+                      dcfp_stream_t stream);
+/* y = act( (x-mean)*rsqrt(var+eps)*gamma + beta (+ residual) ), act = ReLU if relu.
+ * y_nstride: batch stride of y (0 => dense). */
+int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
+                      const float* gamma, const float* beta, float eps,
+                      const float* residual, int relu, float* y, int64_t y_nstride,
+                      int N, int C, int HW, dcfp_stream_t stream);
+/* Backward stage 1: with g = dy * (relu ? y>0 : 1):
+ *   sum_dy[c] = sum g ;  sum_dy_xmu[c] = sum g*(x-mean[c])
+ * (dbeta = sum_dy; dgamma = sum_dy_xmu * rsqrt(var+eps): the per-filter statistic
+ * that feeds the EIC score, pruners/dcfp_pruner.py:18).  y may be NULL iff !relu. */
+int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
+                           const float* y, int64_t y_nstride, const float* mean,
+                           int relu, int N, int C, int HW,
+                           float* sum_dy, float* sum_dy_xmu,
+                           void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
+/* Backward stage 2: dx = gamma*istd*( g - sum_dy/M - (x-mean)*istd^2*sum_dy_xmu/M ),
+ * M = count (N*HW, or the global count under SyncBN); d_residual (nullable) = g. */
+int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
+                          const float* y, int64_t y_nstride, const float* mean,
+                          const float* var, const float* gamma, float eps,
+                          const float* sum_dy, const float* sum_dy_xmu, float count,
+                          int relu, float* dx, float* d_residual,
+                          int N, int C, int HW, dcfp_stream_t stream);
+
+/* ------------------------------------------------- element-wise / pooling
+ * MaxPool2d(3,2,1) (resnet.py:100,149): -inf padding, first-max index. */
+int dcfp_maxpool3x3s2_fwd_f32(const float* x, float* y, int32_t* argmax,
+                              int N, int C, int H, int W, int Hout, int Wout,
+                              dcfp_stream_t stream);
+int dcfp_maxpool3x3s2_bwd_f32(const float* dy, const int32_t* argmax, float* dx,
+                              int N, int C, int H, int W, int Hout, int Wout,
+                              dcfp_stream_t stream);
+/* AdaptiveAvgPool2d(1) (aspp.py:56): y[n,c] = scale * sum_hw x[n,c,:]. */
+int dcfp_rowsum_f32(const float* x, int64_t x_nstride, float* y, float scale,
+                    int N, int C, int HW, dcfp_stream_t stream);
+/* bilinear 1x1 -> HxW (aspp.py:76) = broadcast: y[n,c,:] (+)= scale*v[n,c]. */
+int dcfp_broadcast_hw_f32(const float* v, float scale, float* y, int64_t y_nstride,
+                          int accumulate, int N, int C, int HW, dcfp_stream_t stream);
+/* out = a + b (gradient fan-in); out may alias a. */
+int dcfp_add_f32(const float* a, const float* b, float* out, int64_t n,
+                 dcfp_stream_t stream);
+/* Dropout2d (deeplabv3.py:40) with a host-drawn keep mask: y = x*mask[n,c]. */
+int dcfp_channel_scale_f32(const float* x, const float* mask, float* y,
+                           int N, int C, int HW, dcfp_stream_t stream);
+
+/* --------------------------------------- bilinear upsample (+) cross-entropy
+ * F.interpolate(bilinear, align_corners) (deeplabv3.py:47,50). */
+int dcfp_upsample_bilinear_fwd_f32(const float* x, float* y, int N, int C,
+                                   int h, int w, int H, int W, int align_corners,
+                                   dcfp_stream_t stream);
+int dcfp_upsample_bilinear_bwd_f32(const float* dy, float* dx, int N, int C,
+                                   int h, int w, int H, int W, int align_corners,
+                                   dcfp_stream_t stream);
+/* Fused  F.interpolate -> nn.CrossEntropyLoss(ignore_index, 'mean')
+ * (deeplabv3.py:47,50 + loss/criterion.py:60,65-67): never materialises the
+ * full-resolution logits.  labels: int64 [N,H,W].
+ *   fwd: out[0] = sum over valid pixels of -log_softmax(z)[label];
+ *        out[1] = number of valid pixels (as float).
+ *   bwd: dlogits[n,c,i,j] = grad_scale * sum_pixels weight*(softmax - onehot),
+ *        gathered per low-res cell (deterministic, no atomics).
+ * pixel_keep (nullable, uint8 [N,H,W]): 0 => pixel treated as ignored (OHEM). */
+size_t dcfp_upsample_ce_workspace_bytes(int N, int H, int W);
+/* lse (nullable on fwd): [N,H,W] log-sum-exp of the interpolated logits per pixel,
+ * written by fwd and consumed by bwd (33.5 MB at 4x1024x2048 instead of 637 MB of
+ * full-resolution logits).  gt_prob (nullable): softmax probability of the label
+ * class per pixel (1.0 where the label is ignore_index) — feeds OHEM. */
+int dcfp_upsample_ce_fwd_f32(const float* logits, const int64_t* labels,
+                             const uint8_t* pixel_keep, int ignore_index,
+                             int N, int C, int h, int w, int H, int W, int align_corners,
+                             float* lse, float* gt_prob, float* out2,
+                             void* workspace, size_t workspace_bytes,
+                             dcfp_stream_t stream);
+int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labels,
+                             const uint8_t* pixel_keep, int ignore_index,
+                             int N, int C, int h, int w, int H, int W, int align_corners,
+                             const float* lse, const float* grad_scale /* device scalar */,
+                             float* dlogits, dcfp_stream_t stream);
+
+/* ------------------------------------------------------------- EIC score
+ * dcfp_pruning.step (pruners/dcfp_pruner.py:15-20), all scored BN layers in one
+ * launch.  table: device array of n_layers records; eic is updated in place:
+ *   flag = (g*gamma > 0); t = flag ? |g| : eic; eic = eic*r + t*(1-r)
+ * evaluated exactly in the reference's operation order (two roundings). */
+typedef struct DcfpEicEntry {
+    const float* gamma;
+    const float* grad;
+    float* eic;
+    int32_t n;
+    int32_t pad_;
+} DcfpEicEntry;
+int dcfp_eic_update_f32(const DcfpEicEntry* table, int n_layers, float r,
+                        float one_minus_r /* float(1.0 - double(r)), as torch casts it */,
+                        dcfp_stream_t stream);
+
+/* --------------------------------------------------------- SGD (momentum)
+ * torch.optim.SGD step as built by optimizer.py:24-25 over a list of tensors:
+ *   g' = g + wd*p ; buf = first ? g' : mom*buf + g' ; p -= lr*buf. */
+typedef struct DcfpSgdEntry {
+    float* param;
+    const float* grad;
+    float* momentum_buf;
+    int64_t n;
+    int64_t first_chunk; /* prefix sum of ceil(n / DCFP_SGD_CHUNK) over earlier entries */
+    float weight_decay;
+    int32_t pad_;
+} DcfpSgdEntry;
+#define DCFP_SGD_CHUNK 16384
+int dcfp_sgd_momentum_f32(const DcfpSgdEntry* table, int n_tensors, int64_t total_chunks,
+                          float lr, float momentum, int first_step, dcfp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCFP_HIP_H */

@@ -1,0 +1,194 @@
+"""Per-op parity of the HIP kernels (through the C-ABI) against a CPU fp32/fp64 restatement
+of the ATen ops the reference invokes.  Tolerances: SURVEY.md Appendix D item 1 (per-op
+~1e-5 relative, scaled for long reductions)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def max_err(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil
+    (2, 64, 16, 24, 256, 1, 1, 0, 1),
+    (2, 256, 16, 24, 64, 1, 1, 0, 1),
+    (1, 1024, 8, 8, 256, 1, 1, 0, 1),
+    (2, 47, 9, 13, 95, 1, 1, 0, 1),        # pruned widths, odd pixels
+    (2, 256, 12, 16, 512, 1, 2, 0, 1),      # downsample 1x1 stride 2
+    (2, 64, 16, 24, 64, 3, 1, 1, 1),
+    (2, 256, 16, 24, 256, 3, 1, 2, 2),      # layer3 conv2
+    (1, 96, 20, 28, 64, 3, 1, 4, 4),
+    (1, 128, 24, 40, 160, 3, 1, 12, 12),    # ASPP-like dilation
+    (2, 128, 17, 23, 128, 3, 2, 1, 1),      # layer2.0.conv2 (stride 2), odd sizes
+    (2, 3, 33, 47, 64, 3, 2, 1, 1),         # stem
+    (2, 47, 11, 15, 95, 3, 1, 1, 1),        # pruned widths
+    (2, 256, 16, 24, 19, 1, 1, 0, 1),       # classifier (bias)
+    (2, 2048, 1, 1, 256, 1, 1, 0, 1),       # ASPP image-pool conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(cuda, case):
+    from dcfp_amd import ops
+    N, Cin, H, W, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) if Cout == 19 else None
+    x64 = x.double().requires_grad_(True); w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if b is not None else None
+    y64 = F.conv2d(x64, w64, b64, s, p, d)
+    dy = torch.randn(y64.shape, generator=g)
+    y64.backward(dy.double())
+    y32 = F.conv2d(x, w, b, s, p, d)
+
+    xg = x.to(cuda).requires_grad_(True); wg = w.to(cuda).requires_grad_(True)
+    bg = b.to(cuda).requires_grad_(True) if b is not None else None
+    yg = ops.conv2d(xg, wg, bg, s, p, d)
+    assert tuple(yg.shape) == tuple(y64.shape)
+    yg.backward(dy.to(cuda))
+    torch.cuda.synchronize()
+    K = Cin * k * k
+    tol = 3e-6 * max(1.0, math.sqrt(K) / 8)
+    ref_noise = rel_err(y32, y64)
+    assert rel_err(yg, y64) < max(tol, 3 * ref_noise), ("fwd", rel_err(yg, y64), ref_noise)
+    assert rel_err(xg.grad, x64.grad) < max(tol, 1e-5), ("dgrad", rel_err(xg.grad, x64.grad))
+    assert rel_err(wg.grad, w64.grad) < 2e-5, ("wgrad", rel_err(wg.grad, w64.grad))
+    if b is not None:
+        assert rel_err(bg.grad, b64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape,relu,res", [
+    ((4, 64, 16, 24), True, False), ((2, 256, 9, 13), True, True), ((4, 47, 8, 8), False, False),
+    ((2, 256, 1, 1), True, False), ((3, 128, 33, 31), False, True),
+])
+def test_bn_act_fwd_bwd(cuda, shape, relu, res):
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    r = torch.randn(shape, generator=g) if res else None
+    dy = torch.randn(shape, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+
+    def ref(dt):
+        xx = x.to(dt).requires_grad_(True); gg = gamma.to(dt).requires_grad_(True)
+        bb = beta.to(dt).requires_grad_(True)
+        rr = r.to(dt).requires_grad_(True) if res else None
+        rm_, rv_ = rm.to(dt).clone(), rv.to(dt).clone()
+        y = F.batch_norm(xx, rm_, rv_, gg, bb, True, 0.1, 1e-5)
+        if res:
+            y = y + rr
+        if relu:
+            y = F.relu(y)
+        y.backward(dy.to(dt))
+        return y, xx.grad, gg.grad, bb.grad, (rr.grad if res else None), rm_, rv_
+
+    y64, dx64, dg64, db64, dr64, rm64, rv64 = ref(torch.float64)
+    xg = x.to(cuda).requires_grad_(True); gg = gamma.to(cuda).requires_grad_(True)
+    bg = beta.to(cuda).requires_grad_(True)
+    rg = r.to(cuda).requires_grad_(True) if res else None
+    rmg, rvg = rm.to(cuda), rv.to(cuda)
+    yg = ops.batch_norm_act(xg, gg, bg, rmg, rvg, rg, relu, True, 0.1, 1e-5, False)
+    yg.backward(dy.to(cuda))
+    torch.cuda.synchronize()
+    # ReLU masks may flip for |pre-activation| ~ 1e-7: compare with a small absolute slack
+    assert max_err(yg, y64) < 2e-5
+    assert max_err(rmg, rm64) < 1e-6 and max_err(rvg, rv64) < 1e-5
+    assert rel_err(dg64, gg.grad) < 1e-4 and rel_err(db64, bg.grad) < 1e-4
+    assert rel_err(dx64, xg.grad) < 1e-4
+    if res:
+        assert rel_err(dr64, rg.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 17, 23), (1, 128, 32, 64), (2, 8, 5, 5)])
+def test_maxpool(cuda, shape):
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    x[0, 0, 0, :3] = float("-inf")
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xg = x.to(cuda).requires_grad_(True)
+    yg = ops.maxpool3x3s2(xg)
+    yg.backward(dy.to(cuda))
+    assert torch.equal(yg.cpu(), y.detach())
+    assert max_err(xg.grad, xr.grad) < 1e-6
+
+
+def test_global_pool_broadcast(cuda):
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 9, 13, generator=g)
+    xr = x.clone().requires_grad_(True)
+    v = F.adaptive_avg_pool2d(xr, 1)
+    up = F.interpolate(v, size=(9, 13), mode="bilinear", align_corners=True)
+    dy = torch.randn(up.shape, generator=g)
+    up.backward(dy)
+    xg = x.to(cuda).requires_grad_(True)
+    vg = ops.global_avg_pool(xg)
+    upg = ops.broadcast_to_hw(vg, 9, 13)
+    upg.backward(dy.to(cuda))
+    assert max_err(vg, v) < 1e-6 and max_err(upg, up) < 1e-6
+    assert max_err(xg.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("hw,HW", [((9, 13), (65, 97)), ((8, 8), (64, 64)), ((5, 7), (5, 7)), ((3, 3), (1, 1))])
+def test_upsample_bilinear(cuda, align, hw, HW):
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 5, *hw, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = F.interpolate(xr, size=HW, mode="bilinear", align_corners=align)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xg = x.to(cuda).requires_grad_(True)
+    yg = ops.upsample_bilinear(xg, HW, align)
+    yg.backward(dy.to(cuda))
+    assert max_err(yg, y) < 2e-6
+    assert max_err(xg.grad, xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("hw,HW,C", [((9, 13), (65, 97), 19), ((8, 16), (64, 128), 19), ((5, 5), (33, 33), 7)])
+def test_upsample_ce(cuda, align, hw, HW, C):
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(13)
+    N = 2
+    z = torch.randn(N, C, *hw, generator=g) * 3
+    lab = torch.randint(0, C, (N, *HW), generator=g)
+    lab[torch.rand(N, *HW, generator=g) < 0.1] = 255
+    lab[1, :4] = 255
+    zr = z.double().requires_grad_(True)
+    up = F.interpolate(zr, size=HW, mode="bilinear", align_corners=align)
+    loss = F.cross_entropy(up, lab, ignore_index=255)
+    loss.backward()
+    zg = z.to(cuda).requires_grad_(True)
+    lg = ops.upsample_cross_entropy(zg, lab.to(cuda), HW, align, 255)
+    lg.backward()
+    assert abs(lg.item() - loss.item()) < 2e-6 * max(1.0, abs(loss.item()))
+    assert rel_err(zg.grad, zr.grad) < 2e-5
+
+
+def test_upsample_ce_all_ignored(cuda):
+    from dcfp_amd import ops
+    z = torch.randn(1, 4, 3, 3)
+    lab = torch.full((1, 9, 9), 255, dtype=torch.int64)
+    out = ops.upsample_cross_entropy(z.to(cuda), lab.to(cuda), (9, 9), True, 255)
+    assert math.isnan(out.item())      # torch: mean over zero valid pixels = nan
