@@ -18,7 +18,6 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;   // pixels per K-step
 constexpr int BKP = 20;  // LDS row pitch (floats)
@@ -30,10 +29,9 @@ struct WgradParams {
     long long dy_nstride, x_nstride;
     int N, M, Cin, Nn;
     int H, W, Ho, Wo, P, stride, pad, dil;
-    long long Kpix;
+    int Kpix;
     int kchunk, splits, tiles_m, tiles_n;
     int quad_ok;  // Wo % 4 == 0: the 4 pixels of a quad share (img, oh)
-    int vec_dy;   // 16-byte loads of dy allowed
 };
 
 constexpr unsigned kOob = 0x80000000u;      // > any record count: buffer loads return 0
@@ -55,9 +53,9 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
     const int tile = blockIdx.x - split * tiles;
     const int mt = tile / p.tiles_n, ntile = tile - mt * p.tiles_n;
     const int m0 = mt * BM, n0 = ntile * BN;
-    const long long kbeg = (long long)split * p.kchunk;
-    long long kend = kbeg + p.kchunk;
-    if (kend > p.Kpix) kend = p.Kpix;
+    const int kbeg = split * p.kchunk;   // Kpix < 2^31 is checked on the host
+    int kend = kbeg + p.kchunk;
+    if (kend > p.Kpix || kend < kbeg) kend = p.Kpix;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -67,7 +65,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
 
     // Buffer descriptors based at the first image this split touches (block-uniform);
     // invalid lanes use offset kOob and read 0 without branching.
-    const int img0 = (int)(kbeg / p.P);
+    const int img0 = kbeg / p.P;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.dy + (long long)img0 * p.dy_nstride), 0, kMaxRecords, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -101,14 +99,14 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
 
     float areg[PA][4], breg[PB][4];
 
-    auto load_tile = [&](long long kbase) {
+    auto load_tile = [&](int kbase) {
         // coordinates of this thread's 4 pixels
         int img[4], pp[4], ih[4], iw[4];
         bool qv[4];
-        const long long q0 = kbase + 4 * kx;
+        const int q0 = kbase + 4 * kx;
         if (p.quad_ok) {
-            const int imabs = (int)(q0 / p.P);
-            const int pq = (int)(q0 - (long long)imabs * p.P);
+            const int imabs = q0 / p.P;
+            const int pq = q0 - imabs * p.P;
             const int im = imabs - img0;
             const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
 #pragma unroll
@@ -120,10 +118,10 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const long long q = q0 + e;
+                const int q = q0 + e;
                 qv[e] = q < kend;
-                const int imabs = (int)(q / p.P);
-                const int pq = (int)(q - (long long)imabs * p.P);
+                const int imabs = q / p.P;
+                const int pq = q - imabs * p.P;
                 const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
                 img[e] = imabs - img0; pp[e] = pq;
                 ih[e] = oh * p.stride; iw[e] = ow * p.stride;
@@ -131,20 +129,12 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
         }
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            if (p.vec_dy) {  // block-uniform: quads are 16-byte aligned and all-or-nothing
-                const unsigned off = (a_ok[j] && qv[0])
-                                         ? (unsigned)(img[0] * dyn + a_off[j] + pp[0]) * 4u : kOob;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) areg[j][e] = __builtin_bit_cast(float, v[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned off = (a_ok[j] && qv[e])
-                                             ? (unsigned)(img[e] * dyn + a_off[j] + pp[e]) * 4u : kOob;
-                    areg[j][e] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off, 0, 0));
-                }
+            for (int e = 0; e < 4; ++e) {
+                const unsigned off = (a_ok[j] && qv[e])
+                                         ? (unsigned)(img[e] * dyn + a_off[j] + pp[e]) * 4u : kOob;
+                areg[j][e] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off, 0, 0));
             }
         }
 #pragma unroll
@@ -180,7 +170,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
         load_tile(kbeg);
         store_tile(0);
@@ -192,7 +182,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nk;
-        if (more) load_tile(kbeg + (long long)(kt + 1) * BK);
+        if (more) load_tile(kbeg + (kt + 1) * BK);
         const float* a = As + cur * (BM * BKP) + a_row * BKP + 4 * lhi;
         const float* b = Bs + cur * (BN * BKP) + b_row * BKP + 4 * lhi;
 #pragma unroll
@@ -365,10 +355,10 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     p.N = d->N; p.M = d->Cout; p.Cin = d->Cin; p.Nn = d->Cin * T;
     p.H = d->H; p.W = d->W; p.Ho = d->Hout; p.Wo = d->Wout; p.P = d->Hout * d->Wout;
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
-    p.Kpix = (long long)d->N * p.P;
+    if ((long long)d->N * p.P >= (1LL << 30)) return DCFP_E_UNSUPPORTED;
+    p.Kpix = d->N * p.P;
     p.kchunk = pl.kchunk; p.splits = pl.splits; p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
     p.quad_ok = (d->Wout % 4 == 0) ? 1 : 0;
-    p.vec_dy = p.quad_ok && (p.dy_nstride % 4 == 0) && dcfp_aligned16(dy);
     {   // 31-bit byte offsets relative to the first image of a split
         const long long span = (long long)pl.kchunk / p.P + 2;
         const long long big = p.dy_nstride > p.x_nstride ? p.dy_nstride : p.x_nstride;

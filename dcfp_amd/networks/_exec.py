@@ -1,0 +1,70 @@
+"""Execution helpers: run the reference's leaf modules (nn.Conv2d / nn.BatchNorm2d / nn.ReLU /
+nn.Dropout2d / nn.AdaptiveAvgPool2d — kept as plain torch modules so names, state_dict keys
+and `isinstance` checks in pruners/flops counters stay valid) through the HIP kernels.
+The leaf modules are parameter holders only: their own forward() is never called here."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_BN_TYPES = (nn.BatchNorm2d, nn.SyncBatchNorm)
+
+
+def conv(m, x):
+    if m.groups != 1 or m.kernel_size[0] != m.kernel_size[1] or m.stride[0] != m.stride[1] \
+            or m.padding[0] != m.padding[1] or m.dilation[0] != m.dilation[1] \
+            or isinstance(m.padding, str) or m.padding_mode != "zeros":
+        raise RuntimeError(f"dcfp_amd: unsupported conv configuration {m}")
+    return ops.conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], m.dilation[0])
+
+
+def bn_act(m, x, relu=False, residual=None):
+    """BatchNorm2d / SyncBatchNorm (+ReLU) (+residual add before the ReLU)."""
+    training = m.training or (m.running_mean is None)
+    sync = False
+    if isinstance(m, nn.SyncBatchNorm) and training:
+        sync = m.process_group if m.process_group is not None else True
+    momentum = m.momentum
+    if training and m.track_running_stats and m.num_batches_tracked is not None:
+        m.num_batches_tracked.add_(1)
+        if momentum is None:
+            momentum = 1.0 / float(m.num_batches_tracked)
+    if not m.affine:
+        raise RuntimeError("dcfp_amd: BatchNorm without affine parameters is not on the DCFP path")
+    return ops.batch_norm_act(x, m.weight, m.bias, m.running_mean, m.running_var, residual, relu,
+                              training, momentum, m.eps, sync)
+
+
+def run_sequential(seq, x):
+    """Interpret an nn.Sequential of the reference (stem, downsample, heads, image-pool branch)
+    with conv -> (BN [+ReLU]) peephole fusion."""
+    mods = list(seq.children())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            x = conv(m, x)
+        elif isinstance(m, _BN_TYPES):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = bn_act(m, x, relu=fuse)
+            if fuse:
+                i += 1
+        elif isinstance(m, nn.ReLU):
+            raise RuntimeError("dcfp_amd: bare ReLU outside a BN+ReLU pair is not on the DCFP path")
+        elif isinstance(m, nn.Dropout2d):
+            x = ops.dropout2d(x, m.p, m.training, getattr(m, "fixed_mask", None))
+        elif isinstance(m, nn.AdaptiveAvgPool2d):
+            x = ops.global_avg_pool(x)
+        elif isinstance(m, nn.Identity):
+            pass
+        else:
+            raise RuntimeError(f"dcfp_amd: no HIP path for module {type(m).__name__}")
+        i += 1
+    return x
+
+
+def require_device(x):
+    if not x.is_cuda:
+        raise RuntimeError(
+            "dcfp_amd networks run on the MI355X HIP kernels only: move the model and inputs to "
+            "cuda (the CPU restatement used for checking lives under oracle/, not in the product)")

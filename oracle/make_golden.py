@@ -1,0 +1,264 @@
+"""Generate tests/golden/*.npz by IMPORTING THE REAL REFERENCE (/root/reference) on CPU.
+
+Dev-container only (the reference never travels to the GPU box).  Run:
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/oracle/make_golden.py
+Accommodations — none of them touches a reference file:
+  * `ordered_set` (third-party, un-vendored) -> an insertion-ordered list stand-in;
+  * torch 2.x names conv's autograd node 'ConvolutionBackward0' -> registered at run time;
+  * backbone_para['pretrained'] = False (weights are downloaded files in the reference);
+  * Dropout2d.p forced to 0 in the deep-supervision head for deterministic goldens.
+Inputs/weights are closed-form (oracle/fill.py), so fixtures hold only outputs.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+
+class OrderedSet(list):
+    def __init__(self, it=()):
+        super().__init__()
+        for x in it:
+            self.add(x)
+
+    def add(self, x):
+        if x not in self:
+            self.append(x)
+
+    def intersection(self, o):
+        return OrderedSet(x for x in self if x in o)
+
+    def union(self, o):
+        return OrderedSet(list(self) + list(o))
+
+
+_m = types.ModuleType("ordered_set")
+_m.OrderedSet = OrderedSet
+sys.modules["ordered_set"] = _m
+
+import networks  # noqa: E402  (reference)
+import pruners  # noqa: E402
+import pruners.channel_pruner as cp  # noqa: E402
+import pruners.dcfp_pruner as dp  # noqa: E402
+from loss.criterion import build_criterions  # noqa: E402
+from loss.ohem import OhemCrossEntropy2d  # noqa: E402
+import optimizer as ref_optimizer  # noqa: E402
+
+cp.CONV += ("ConvolutionBackward",)
+cp.NON_PASS = cp.CONV + cp.FC
+cp.BACKWARD_PARSER_DICT["ConvolutionBackward"] = cp.ChannelPruner.conv_backward_parser
+
+from oracle import fill  # noqa: E402
+from oracle.make_scores import synthetic_scores  # noqa: E402
+
+BB_PARA = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
+
+
+class _DS:
+    ignore_label = 255
+    num_classes = 19
+    class_weights = None
+
+
+def build_ref(model, backbone, align, dtype):
+    crit = build_criterions("ce", _DS(), {"ds_weight": 0.4})
+    cls = getattr(networks, model).Seg_Model
+    m = cls(backbone=backbone, backbone_para=dict(BB_PARA), model_para={}, num_classes=19,
+            align_corner=align, criterion=crit, deepsup=True)
+    m.load_state_dict(fill.closed_form_state(m.state_dict()))
+    m.conv_deepsup[3].p = 0.0
+    return m.to(dtype)
+
+
+def whole_model(tag, model, backbone, N, H, W, align):
+    res = {}
+    for dtype, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        torch.manual_seed(0)
+        m = build_ref(model, backbone, align, dtype)
+        m.train()
+        x = fill.closed_form_input(N, H, W, dtype)
+        lab = fill.closed_form_labels(N, H, W)
+        out = m(x, lab, deepsup=True)
+        loss = out["loss"]
+        loss.backward()
+        grads = {k: p.grad.detach() for k, p in m.named_parameters()}
+        bn_names = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+        res["loss" + sfx] = np.array(loss.item(), dtype=np.float64)
+        res["bn_wgrad" + sfx] = torch.cat([grads[n + ".weight"].reshape(-1) for n in bn_names]).numpy()
+        res["bn_bgrad" + sfx] = torch.cat([grads[n + ".bias"].reshape(-1) for n in bn_names]).numpy()
+        for cname in ("backbone.conv1.0", "backbone.layer1.0.conv1", "backbone.layer2.0.conv2", "last_conv.6"):
+            res["wgrad:" + cname + ":" + sfx] = grads[cname + ".weight"].numpy()
+        res["bgrad:last_conv.6:" + sfx] = grads["last_conv.6.bias"].numpy()
+        # every parameter gradient, compactly: L2 norm and a projection on a fixed cos vector
+        pnames = [k for k, _ in m.named_parameters()]
+        res["grad_l2:" + sfx] = np.array([float(grads[k].double().norm()) for k in pnames])
+        res["grad_proj:" + sfx] = np.array([
+            float((grads[k].double().reshape(-1) * torch.cos(0.37 * torch.arange(grads[k].numel(), dtype=torch.float64))).sum())
+            for k in pnames])
+        if sfx == "32":
+            res["param_names"] = np.array(pnames)
+        # running stats after the training-mode forward
+        sd = m.state_dict()
+        res["rm:backbone.bn1:" + sfx] = sd["backbone.bn1.running_mean"].numpy()
+        res["rv:backbone.bn1:" + sfx] = sd["backbone.bn1.running_var"].numpy()
+        # logits of both heads: second (eval-free) pass in train mode would re-update stats, so
+        # take them from a fresh identical model
+        m2 = build_ref(model, backbone, align, dtype)
+        m2.train()
+        with torch.no_grad():
+            outs = m2(x, None, deepsup=True)
+        # stored at every 2nd pixel (fixture size); fp64 kept as the difference to fp32
+        if sfx == "32":
+            l32 = [o[:, :, ::2, ::2].clone() for o in outs]
+            res["logits32"] = l32[0].numpy()
+            res["logits_ds32"] = l32[1].numpy()
+        else:
+            res["logits_d64m32"] = (outs[0][:, :, ::2, ::2] - l32[0].double()).float().numpy()
+            res["logits_ds_d64m32"] = (outs[1][:, :, ::2, ::2] - l32[1].double()).float().numpy()
+        if sfx == "32":
+            res["bn_names"] = np.array(bn_names)
+            res["state_keys"] = np.array(list(sd.keys()))
+            res["state_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+            res["ignore_prune_layer"] = np.array(m.ignore_prune_layer)
+    res["meta"] = np.array([N, H, W, int(align)])
+    np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **res)
+    print("wrote", tag, "loss32", res["loss32"], "loss64", res["loss64"])
+
+
+def eic_trajectory():
+    """dcfp_pruning.step over 4 steps on hand-made (gamma, grad) incl. sign flips, exact
+    zeros and the python-int-0 start (pruners/dcfp_pruner.py:13-20)."""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn_a = torch.nn.BatchNorm2d(37)
+            self.bn_b = torch.nn.BatchNorm2d(64)
+            self.skip = torch.nn.BatchNorm2d(8)
+            self.ignore_prune_layer = ["skip"]
+    net = Net()
+    tp = dp.dcfp_pruning(net, 0.999)
+    rec = {}
+    for step in range(4):
+        for j, (name, bn) in enumerate((("bn_a", net.bn_a), ("bn_b", net.bn_b), ("skip", net.skip))):
+            n = bn.weight.numel()
+            i = torch.arange(n, dtype=torch.float64)
+            gamma = (0.4 + torch.cos(0.9 * i + j + 0.3 * step)).float()
+            grad = (1e-3 * torch.cos(1.7 * i + 2 * j + 1.1 * step) * (1 + i % 3)).float()
+            grad[(i % 7 == 0)] = 0.0          # exact zeros
+            if step >= 2:
+                grad[(i % 5 == 1)] *= -1       # sign flips against the earlier steps
+            bn.weight.data.copy_(gamma)
+            bn.weight.grad = grad.clone()
+            rec[f"gamma:{name}:{step}"] = gamma.numpy()
+            rec[f"grad:{name}:{step}"] = grad.numpy()
+        tp.step(net)
+        for name in ("bn_a", "bn_b"):
+            rec[f"eic:{name}:{step}"] = tp.get_eic()["eic"][name].clone().numpy()
+    rec["names"] = np.array(list(tp.get_eic()["eic"].keys()))
+    np.savez_compressed(os.path.join(OUT, "eic_trajectory.npz"), **rec)
+    print("wrote eic_trajectory", rec["names"])
+
+
+def masks_and_surgery():
+    for gp in (0.5, 0.7):
+        torch.manual_seed(0)
+        m = build_ref("deeplabv3", "resnet50", True, torch.float32)
+        m.criterion = None
+        eic = synthetic_scores(m)
+        score_path = "/tmp/_golden_score.pth"
+        torch.save({"eic": eic}, score_path)
+        pruner = dp.DCFPPruner(global_percent=gp, layer_keep=0.02, score_file=score_path)
+        import copy
+        pruned, channel_cfg = pruner.prune_model(copy.deepcopy(m), except_start_keys=["conv_deepsup"])
+        th = pruner.get_thresh()
+        rec = {"thresh": np.array([float(th[0]), float(th[1])], dtype=np.float32),
+               "names": np.array(list(channel_cfg.keys())),
+               "norm_conv_bn": np.array(list(pruner.norm_conv_links.keys())),
+               "norm_conv_conv": np.array(list(pruner.norm_conv_links.values())),
+               "except_layers": np.array(pruner.except_layers),
+               "groups": np.array([",".join(sorted(g)) for g in pruner.same_out_channel_groups.values()])}
+        for name, cfg in channel_cfg.items():
+            if "in_mask" in cfg:
+                rec["in:" + name] = np.packbits(cfg["in_mask"].reshape(-1).astype(np.uint8))
+                rec["in_n:" + name] = np.array([cfg["in_channels"], cfg["raw_in_channels"]])
+            if "out_mask" in cfg:
+                rec["out:" + name] = np.packbits(cfg["out_mask"].reshape(-1).astype(np.uint8))
+                rec["out_n:" + name] = np.array([cfg["out_channels"], cfg["raw_out_channels"]])
+        sd = pruned.state_dict()
+        rec["pruned_keys"] = np.array(list(sd.keys()))
+        rec["pruned_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        rec["pruned_sum"] = np.array([float(v.double().sum()) for v in sd.values()])
+        rec["pruned_abs"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+        # slim model rebuilt by init_pruned_model + forward sanity (prune.py:100-110)
+        slim = build_ref("deeplabv3", "resnet50", True, torch.float32)
+        slim.criterion = None
+        pruners.init_pruned_model(slim, channel_cfg)
+        rec["slim_shapes"] = np.array([str(tuple(v.shape)) for v in slim.state_dict().values()])
+        slim.load_state_dict(sd)
+        slim.eval()
+        with torch.no_grad():
+            y = slim(fill.closed_form_input(2, 33, 33), None, deepsup=True)
+        rec["slim_logits"] = y[0].numpy()
+        np.savez_compressed(os.path.join(OUT, f"prune_v3r50_gp{int(gp * 100)}.npz"), **rec)
+        print("wrote prune golden gp", gp, "thresh", rec["thresh"],
+              "kept", sum(int(c.get("out_channels", 0)) for c in channel_cfg.values()))
+
+
+def ohem_cases():
+    rec = {}
+    crit = OhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=100000)
+    # (zoomed map is H/8 x W/8; min_kept is divided by 64 inside find_threshold)
+    cases = {"kth_le": (2, 5, 64, 64, 0.3, 64 * 20), "kth_gt": (2, 5, 64, 64, 9.0, 64 * 3),
+             "few_valid": (1, 5, 32, 32, 1.0, 100000)}
+    for tag, (n, c, h, w, sharp, mk) in cases.items():
+        i = torch.arange(n * c * h * w, dtype=torch.float64)
+        z = (0.3 * torch.cos(2.1 * i)).reshape(n, c, h, w)
+        lab = fill.closed_form_labels(n, h, w, num_classes=c)
+        onehot = torch.nn.functional.one_hot(lab.clamp(max=c - 1), c).permute(0, 3, 1, 2).double()
+        wob = (0.5 + 0.5 * torch.cos(0.0031 * torch.arange(n * h * w, dtype=torch.float64))).reshape(n, 1, h, w)
+        if tag == "kth_gt":
+            wob = 0.9 + 0.1 * wob
+        z = (z + sharp * onehot * wob).float()   # label-class logit boosted by a varying margin
+        prob = torch.softmax(z, 1).numpy()
+        lab = lab.numpy()
+        crit.min_kept = mk
+        th = crit.find_threshold(prob, lab)
+        rec[f"z:{tag}"] = z.numpy(); rec[f"lab:{tag}"] = lab
+        rec[f"th:{tag}"] = np.array(float(th)); rec[f"min_kept:{tag}"] = np.array(crit.min_kept)
+        print("ohem", tag, th)
+    np.savez_compressed(os.path.join(OUT, "ohem_threshold.npz"), **rec)
+
+
+def lr_schedule():
+    rec = {"poly": np.array([ref_optimizer.lr_poly(0.01, i, 4000, 0.9) for i in (0, 1, 1999, 3999)]),
+           "warm": np.array([ref_optimizer.lr_warmup(0.01, i, 1000) for i in (0, 1, 500, 999, 1000)])}
+    np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), **rec)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["eic", "lr", "ohem", "simple", "v3r50", "v3r101", "prune"]
+    if "eic" in which:
+        eic_trajectory()
+    if "lr" in which:
+        lr_schedule()
+    if "ohem" in which:
+        ohem_cases()
+    if "simple" in which:
+        whole_model("simple_r50_4x64x64", "simple", "resnet50", 4, 64, 64, False)
+    if "v3r50" in which:
+        whole_model("v3_r50_2x65x65", "deeplabv3", "resnet50", 2, 65, 65, True)
+    if "v3r101" in which:
+        whole_model("v3_r101_2x65x65", "deeplabv3", "resnet101", 2, 65, 65, True)
+    if "prune" in which:
+        masks_and_surgery()

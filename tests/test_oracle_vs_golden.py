@@ -1,0 +1,115 @@
+"""CPU: the oracle (oracle/, a restatement of the reference's algorithm) against golden vectors
+produced by importing the real reference (oracle/make_golden.py).  This is what pins the
+oracle; the GPU tests then compare the HIP path with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill, masks, model as omodel, ohem as oohem, scoring
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    path = os.path.join(G, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path, allow_pickle=False)
+
+
+def test_eic_trajectory_bit_exact():
+    g = _load("eic_trajectory.npz")
+    for name in g["names"]:
+        eic = 0
+        for step in range(4):
+            eic = scoring.eic_step(g[f"gamma:{name}:{step}"], g[f"grad:{name}:{step}"], eic, 0.999)
+            ref = g[f"eic:{name}:{step}"]
+            assert eic.dtype == np.float32 and np.array_equal(eic, ref), (name, step)
+        # exact zeros stay exact zeros
+        assert (eic == 0).sum() == (ref == 0).sum()
+
+
+def test_lr_schedule():
+    g = _load("lr_schedule.npz")
+    assert np.array_equal(g["poly"], np.array([scoring.lr_poly(0.01, i, 4000, 0.9) for i in (0, 1, 1999, 3999)]))
+    assert np.array_equal(g["warm"], np.array([scoring.lr_warmup(0.01, i, 1000) for i in (0, 1, 500, 999, 1000)]))
+
+
+def test_ohem_threshold():
+    g = _load("ohem_threshold.npz")
+    for tag in ("kth_le", "kth_gt", "few_valid"):
+        prob = torch.softmax(torch.from_numpy(g[f"z:{tag}"]), 1).numpy()
+        th = oohem.find_threshold(prob, g[f"lab:{tag}"], 255, 0.7, int(g[f"min_kept:{tag}"]))
+        assert float(th) == float(g[f"th:{tag}"]), tag
+
+
+MODELS = [("simple_r50_4x64x64", "simple", "resnet50"), ("v3_r50_2x65x65", "deeplabv3", "resnet50"),
+          ("v3_r101_2x65x65", "deeplabv3", "resnet101")]
+
+
+def product_state(model_name, backbone, align):
+    """state_dict (names/shapes) of the product module tree, closed-form filled."""
+    from dcfp_amd import networks
+    m = getattr(networks, model_name).Seg_Model(
+        backbone=backbone, backbone_para={"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False},
+        num_classes=19, align_corner=align, deepsup=True)
+    return m, fill.closed_form_state(m.state_dict())
+
+
+@pytest.mark.parametrize("tag,model_name,backbone", MODELS)
+def test_state_dict_contract(tag, model_name, backbone):
+    g = _load(f"model_{tag}.npz")
+    m, sd = product_state(model_name, backbone, bool(g["meta"][3]))
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["state_shapes"])
+    assert m.ignore_prune_layer == list(g["ignore_prune_layer"])
+
+
+@pytest.mark.parametrize("tag,model_name,backbone", MODELS[:2])
+def test_oracle_model_matches_reference(tag, model_name, backbone):
+    g = _load(f"model_{tag}.npz")
+    N, H, W, align = [int(v) for v in g["meta"]]
+    _, sd0 = product_state(model_name, backbone, bool(align))
+    cfg = omodel.Cfg(model=model_name, backbone=backbone, align_corner=bool(align))
+    sd = omodel.clone_state(sd0)
+    x, lab = fill.closed_form_input(N, H, W), fill.closed_form_labels(N, H, W)
+    outs, loss, _ = omodel.seg_forward(sd, x, cfg, lab, training=True)
+    loss.backward()
+    # same ATen CPU ops as the reference: agreement far below the fp32-vs-fp64 noise floor
+    noise = np.abs(g["logits_d64m32"]).max()
+    d = np.abs(outs[0][:, :, ::2, ::2].detach().numpy() - g["logits32"]).max()
+    dds = np.abs(outs[1][:, :, ::2, ::2].detach().numpy() - g["logits_ds32"]).max()
+    assert d <= max(1e-5, 0.1 * noise) and dds <= max(1e-5, 0.1 * noise), (d, dds, noise)
+    assert abs(float(loss) - float(g["loss32"])) < 2e-6
+    bn_w = torch.cat([sd[n + ".weight"].grad.reshape(-1) for n in g["bn_names"]]).numpy()
+    ref = g["bn_wgrad32"]
+    rel = np.linalg.norm(bn_w - ref) / np.linalg.norm(ref)
+    noise_rel = np.linalg.norm(g["bn_wgrad64"] - ref) / np.linalg.norm(g["bn_wgrad64"])
+    assert rel <= max(1e-4, 0.5 * noise_rel), (rel, noise_rel)
+    for key in ("backbone.conv1.0", "backbone.layer2.0.conv2", "last_conv.6"):
+        a = sd[key + ".weight"].grad.numpy(); b = g[f"wgrad:{key}:32"]
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-3, key
+    assert np.abs(sd["backbone.bn1.running_mean"].numpy() - g["rm:backbone.bn1:32"]).max() < 1e-6
+    assert np.abs(sd["backbone.bn1.running_var"].numpy() - g["rv:backbone.bn1:32"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("gp", [50, 70])
+def test_oracle_masks_match_reference(gp):
+    """Threshold + per-layer mask arithmetic of the oracle vs DCFPPruner in the reference."""
+    g = _load(f"prune_v3r50_gp{gp}.npz")
+    m, sd0 = product_state("deeplabv3", "resnet50", True)
+    from oracle.make_scores import synthetic_scores
+    eic = synthetic_scores(m)
+    links = dict(zip(g["norm_conv_bn"].tolist(), g["norm_conv_conv"].tolist()))
+    exc = set(g["except_layers"].tolist())
+    th = masks.thresholds(eic, list(links.keys()), exc, gp / 100.0)
+    assert np.array_equal(np.array([float(th[0]), float(th[1])], dtype=np.float32), g["thresh"])
+    om = masks.out_masks(eic, links, exc, th, 0.02)
+    groups = [set(s.split(",")) for s in g["groups"].tolist()]
+    for conv, mask in om.items():
+        if any(conv in grp for grp in groups):
+            continue   # residual groups take the union of their members: checked in test_pruner_host
+        ref = np.unpackbits(g["out:" + conv])[:mask.numel()]
+        assert np.array_equal(mask.numpy().astype(np.uint8), ref), conv
