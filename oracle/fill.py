@@ -10,6 +10,15 @@ def _wave(n, a, b, dtype=torch.float64):
     return torch.cos(a * i + b).to(dtype)
 
 
+def _noise(n, a, b):
+    """Closed-form pseudo-random values in [-sqrt(3), sqrt(3)) (unit variance, no periodic
+    structure): frac(sin(a*i + b) * 43758.5453) evaluated in float64."""
+    i = torch.arange(n, dtype=torch.float64)
+    u = torch.sin((a * i + b) % 6.283185307179586) * 43758.5453123
+    u = u - torch.floor(u)
+    return (u - 0.5) * (2.0 * math.sqrt(3.0))
+
+
 def closed_form_state(state_dict, gamma_amp=0.2, gamma_mid=1.0):
     """Fill every tensor of a state_dict (in its own order) from cos(a*i + b):
     conv weights ~ kaiming scale, BN gamma = mid + amp*cos, beta / biases = 0.1*cos,
@@ -29,7 +38,7 @@ def closed_form_state(state_dict, gamma_amp=0.2, gamma_mid=1.0):
             v = 1.0 + 0.1 * _wave(n, 0.53, b)
         elif t.dim() == 4:
             fan_in = t.shape[1] * t.shape[2] * t.shape[3]
-            v = math.sqrt(2.0 / fan_in) * math.sqrt(2.0) * _wave(n, 0.6180339887 + 1e-3 * idx, b)
+            v = math.sqrt(2.0 / fan_in) * _noise(n, 12.9898 + 1e-3 * idx, 78.233 * (idx + 1))
         elif name.endswith(".weight") and (name[:-len("weight")] + "running_mean") in state_dict:
             v = gamma_mid + gamma_amp * _wave(n, 0.7, b)
         else:
@@ -40,7 +49,7 @@ def closed_form_state(state_dict, gamma_amp=0.2, gamma_mid=1.0):
 
 def closed_form_input(N, H, W, dtype=torch.float32):
     n = N * 3 * H * W
-    x = 1.5 * _wave(n, 0.0137, 0.3) + 0.5 * _wave(n, 1.618, 1.1)
+    x = 0.7 * _wave(n, 0.0137, 0.3) + 0.9 * _noise(n, 4.1414, 0.77)
     return x.reshape(N, 3, H, W).to(dtype)
 
 
