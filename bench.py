@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py — training images/s of DeepLabv3-R101 (+ASPP, os=8) at 4x3x1024x2048 per GPU on
+N MI355X (BASELINE.json metric; config (3) at N=1, config (4) at N>1).
+
+A step is the reference's iteration (train.py:255-270): zero_grad -> poly LR -> forward (CE +
+0.4*deep-supervision CE, fused with the 8x bilinear upsample) -> loss all-reduce/.item() ->
+backward (DDP bucketed gradient all-reduce over RCCL, SyncBN statistics exchange) ->
+dcfp_pruning.step (EIC) -> SGD step.  Synthetic data (images N(0,1), labels uniform 0..18 with
+5 % ignore=255, seed 12345+rank), default-init weights.  One process per GPU; launched for N>1
+as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+
+Prints ONE JSON line with the throughput, a `roofline` object for the dominant conv kernel
+(algorithmic FLOPs / live HIP-event time of its launches in one instrumented step) and, at
+N=1, a `cpu_baseline` object (the CPU oracle timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no TF32 on gfx950
+PEAK_HBM = 8.0e12
+
+
+class _DS:
+    ignore_label = 255
+    num_classes = 19
+    class_weights = None
+
+
+class _OptArgs:
+    no_decay = None
+    optim = "sgd"
+    momentum = 0.9
+    learning_rate = 0.01
+    weight_decay = 5e-4
+
+
+def synthetic_batch(n, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(n, 3, h, w, generator=g)
+    labels = torch.randint(0, 19, (n, h, w), generator=g)
+    labels[torch.rand(n, h, w, generator=g) < 0.05] = 255
+    return images.to(device), labels.to(device)
+
+
+def build_model(backbone, device):
+    from dcfp_amd import networks
+    from dcfp_amd.loss.criterion import build_criterions
+    crit = build_criterions("ce", _DS(), {"ds_weight": 0.4})
+    bb = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
+    model = networks.deeplabv3.Seg_Model(backbone=backbone, backbone_para=bb, model_para={}, num_classes=19,
+                                         align_corner=True, criterion=crit, deepsup=True)
+    return model.to(device).train()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota
+    (a 1-GPU box exposes all host cores but grants a 16-CPU share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cap = int(os.environ.get("DCFP_CPU_THREADS", "16"))
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(backbone, n, h, w, full_hw):
+    """The CPU oracle (a port of the reference's CPU path) on a bounded sample: the same model
+    at batch `n` (ASPP image-pool BN needs >= 2) and h x w pixels; images/s are scaled by the
+    pixel ratio to the full 1024x2048 workload."""
+    from dcfp_amd import networks
+    from oracle import model as omodel
+    from oracle.train_step import CpuTrainer
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(12345)
+    bb = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
+    m = networks.deeplabv3.Seg_Model(backbone=backbone, backbone_para=bb, num_classes=19, align_corner=True,
+                                     deepsup=True)
+    cfg = omodel.Cfg("deeplabv3", backbone, align_corner=True)
+    tr = CpuTrainer(m.state_dict(), cfg, lr=0.01)
+    del m
+    g = torch.Generator().manual_seed(12345)
+    x = torch.randn(n, 3, h, w, generator=g)
+    lab = torch.randint(0, 19, (n, h, w), generator=g)
+    lab[torch.rand(n, h, w, generator=g) < 0.05] = 255
+    mask = torch.ones(n, 512)
+    t0 = time.perf_counter()
+    tr.step(x, lab, dropout_mask=mask)
+    dt = time.perf_counter() - t0
+    scale = (h * w) / float(full_hw[0] * full_hw[1])
+    return {"value": (n / dt) * scale, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 step of the CPU oracle (oracle/train_step.py), DeepLabv3-{backbone} batch {n} at "
+                      f"{h}x{w} ({dt:.1f} s), images/s scaled by the pixel ratio {scale:.4f} to 1024x2048"}
+
+
+def roofline_from_profile(recs, images_per_step, step_s):
+    """Aggregate one instrumented step by kernel instance; the dominant one (by time) is reported."""
+    from dcfp_amd import ops, _lib
+    which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD}
+    agg = {}
+    conv_flops = conv_ms = bn_bytes = bn_ms = 0.0
+    for kind, key, work, ms in recs:
+        if kind in which:
+            name = ops.conv_kernel_name(key, which[kind])
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += work; a[1] += ms; a[2] += 1
+            conv_flops += work; conv_ms += ms
+        else:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += work; a[1] += ms; a[2] += 1
+            bn_bytes += work; bn_ms += ms
+    convs = {k: v for k, v in agg.items() if "kernel<" in k}
+    dom = max(convs, key=lambda k: convs[k][1])
+    w, ms, cnt = convs[dom]
+    roof = {"bound": "mfma", "kernel": dom, "achieved": w / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / PEAK_F32_MFMA, "traffic": None,
+            "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "flop_per_launch": w / cnt,
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+    others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1], "launches": v[2]}
+              for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])}
+    hbm = {k: {"GB/s": v[0] / (v[1] * 1e-3) / 1e9, "ms_per_step": v[1], "launches": v[2]}
+           for k, v in agg.items() if "kernel<" not in k}
+    extra = {"conv_ms_per_step": conv_ms, "conv_TFLOP/s_over_all_convs": conv_flops / (conv_ms * 1e-3) / 1e12,
+             "bn_ms_per_step": bn_ms, "bn_GB/s": bn_bytes / (bn_ms * 1e-3) / 1e9 if bn_ms else None,
+             "step_conv_roofline_frac": conv_flops / step_s / PEAK_F32_MFMA,
+             "conv_kernels": others, "hbm_kernels": hbm}
+    return roof, extra
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--backbone", default="resnet101")
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--size", default="1024,2048")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", default="2,256,512", help="n,h,w of the CPU baseline sample")
+    args, _ = ap.parse_known_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the HIP path: no GPU visible")
+    from dcfp_amd import _lib
+    _lib.lib()  # fail loudly if libdcfp_hip.so is missing
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+    H, W = [int(v) for v in args.size.split(",")]
+
+    from dcfp_amd import optimizer as opt, pruners, ops
+    from dcfp_amd.engine import Engine
+    torch.manual_seed(12345 + rank)           # train.py:166-171
+    seg_model = build_model(args.backbone, device)
+    optimizer = opt.build_optimizer(_OptArgs, seg_model)
+    optimizer.zero_grad()
+    train_pruning = pruners.dcfp_pruning(seg_model, 0.999)
+    engine = Engine(custom_parser=argparse.ArgumentParser())
+    model = engine.data_parallel(seg_model) if world > 1 else seg_model
+    images, labels = synthetic_batch(args.batch, H, W, 12345 + rank, device)
+    max_iter = 4000
+
+    def step(it):
+        optimizer.zero_grad(set_to_none=False)
+        opt.adjust_learning_rate(optimizer, 0.01, it, max_iter, 0.9, -1)
+        loss = model(images, labels, deepsup=True)
+        reduce_loss = engine.all_reduce_tensor(loss["loss"]) if world > 1 else loss["loss"]
+        val = reduce_loss.item()              # the reference syncs here every iteration (train.py:263)
+        if val != val:
+            raise RuntimeError("loss is NaN")
+        loss["loss"].backward()
+        train_pruning.step(seg_model)
+        optimizer.step()
+        return val
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        step(it); it += 1
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step(it); it += 1
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    global_batch = args.batch * world
+    value = global_batch * args.steps / dt
+    step_s = dt / args.steps
+
+    roof, extra = None, None
+    if not args.no_roofline:
+        ops.profile_start()
+        step(it); it += 1
+        recs = ops.profile_stop()
+        if rank == 0:
+            roof, extra = roofline_from_profile(recs, args.batch, step_s)
+    fence()
+    peak_mem = torch.cuda.max_memory_allocated() / 2**30
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n, h, w = [int(v) for v in args.cpu_sample.split(",")]
+        cpu = cpu_baseline(args.backbone, n, h, w, (H, W))
+
+    if rank == 0:
+        out = {"metric": "training images/sec at 1024x2048 DeepLabv3-R101", "value": value, "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": f"DeepLabv3-{args.backbone}+ASPP os8, {args.batch}x3x{H}x{W} per GPU, "
+                                      "CE+0.4*deepsup CE (fused upsample), SyncBN+DDP, EIC step, SGD m0.9 wd5e-4",
+                          "global_batch": global_batch, "parallelism": f"dp{world}"},
+               "final_loss": last, "peak_mem_GiB": peak_mem,
+               "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone) == (1024, 2048, "resnet101") else None,
+               "roofline": roof, "cpu_baseline": cpu, "detail": extra}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@
 // K-step).  With the 4x4 wave tile a K-step is 128 MFMAs (8192 cycles/SIMD) against ~40
 // staging instructions per lane, which is why plain predicated dword loads suffice.
 #include "common.h"
+#include <stdio.h>
 
 namespace {
 
@@ -258,23 +259,43 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     DCFP_RETURN_LAUNCH();
 }
 
-template <int TAPS>
-int launch_taps(IgemmParams& p, hipStream_t stream) {
-    if (p.sd > 1) return launch_cfg<TAPS, 2, 4, 2, 2, true>(p, stream);  // rare: one config
-    // Pick the largest tile that still yields >= ~1 block per CU.
+// Tile choice: the largest tile that still yields >= ~1 block per CU.
+// 0: 32x512  1: 64x512  2: 128x256  3: 128x128  4: 256x256  5: 128x256 strided-dgrad
+int pick_cfg(const IgemmParams& p) {
+    if (p.sd > 1) return 5;
     const long long px = (long long)p.N * p.P;
     auto blocks = [&](int bm, int bn) {
         return ((long long)(p.M + bm - 1) / bm) * ((px + bn - 1) / bn);
     };
-    if (p.M <= 32) return launch_cfg<TAPS, 1, 4, 1, 4>(p, stream);                 // 32 x 512
-    if (p.M <= 64) return launch_cfg<TAPS, 2, 4, 1, 4>(p, stream);                 // 64 x 512
-    if (p.M <= 128) {
-        if (blocks(128, 256) >= 192) return launch_cfg<TAPS, 2, 4, 2, 2>(p, stream);  // 128 x 256
-        return launch_cfg<TAPS, 2, 2, 2, 2>(p, stream);                               // 128 x 128
+    if (p.M <= 32) return 0;
+    if (p.M <= 64) return 1;
+    if (p.M <= 128) return blocks(128, 256) >= 192 ? 2 : 3;
+    if (blocks(256, 256) >= 192) return 4;
+    if (blocks(128, 256) >= 192) return 2;
+    return 3;
+}
+
+const char* cfg_args(int cfg) {
+    switch (cfg) {
+        case 0: return "1,4,1,4,0";
+        case 1: return "2,4,1,4,0";
+        case 2: return "2,4,2,2,0";
+        case 3: return "2,2,2,2,0";
+        case 4: return "4,4,2,2,0";
+        default: return "2,4,2,2,1";
     }
-    if (blocks(256, 256) >= 192) return launch_cfg<TAPS, 4, 4, 2, 2>(p, stream);   // 256 x 256
-    if (blocks(128, 256) >= 192) return launch_cfg<TAPS, 2, 4, 2, 2>(p, stream);   // 128 x 256
-    return launch_cfg<TAPS, 2, 2, 2, 2>(p, stream);                                // 128 x 128
+}
+
+template <int TAPS>
+int launch_taps(IgemmParams& p, hipStream_t stream) {
+    switch (pick_cfg(p)) {
+        case 0: return launch_cfg<TAPS, 1, 4, 1, 4>(p, stream);
+        case 1: return launch_cfg<TAPS, 2, 4, 1, 4>(p, stream);
+        case 2: return launch_cfg<TAPS, 2, 4, 2, 2>(p, stream);
+        case 3: return launch_cfg<TAPS, 2, 2, 2, 2>(p, stream);
+        case 4: return launch_cfg<TAPS, 4, 4, 2, 2>(p, stream);
+        default: return launch_cfg<TAPS, 2, 4, 2, 2, true>(p, stream);
+    }
 }
 
 int check_desc(const DcfpConvDesc* d) {
@@ -297,6 +318,21 @@ int check_desc(const DcfpConvDesc* d) {
 }  // namespace
 
 extern "C" int dcfp_abi_version(void) { return 1; }
+
+// implemented in conv_wgrad.hip
+int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len);
+
+extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_len) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!buf || buf_len <= 0) return DCFP_E_BADDESC;
+    if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_kernel_name(d, buf, buf_len);
+    IgemmParams p;
+    p.N = d->N;
+    if (pass == DCFP_CONV_FWD) { p.M = d->Cout; p.P = d->Hout * d->Wout; p.sd = 1; }
+    else { p.M = d->Cin; p.P = d->H * d->W; p.sd = d->stride; }
+    return snprintf(buf, buf_len, "igemm_kernel<%d,%s>", d->KH * d->KW, cfg_args(pick_cfg(p)));
+}
 
 extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                                         const float* bias, float* y, int64_t y_nstride,

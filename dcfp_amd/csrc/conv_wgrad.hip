@@ -14,6 +14,7 @@
 // As[m][k], Bs[n][k] (row pitch 20 floats: conflict-free ds_read_b128), and one
 // 16-byte read per lane feeds FOUR consecutive k-steps of a 32x32x2 MFMA tile.
 #include "common.h"
+#include <stdio.h>
 
 namespace {
 
@@ -327,6 +328,12 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 }
 
 }  // namespace
+
+int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
+    const Plan pl = make_plan(d);
+    const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : "2,2,1,1";
+    return snprintf(buf, buf_len, "wgrad_kernel<%d,%s>", d->KH * d->KW, args);
+}
 
 extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
     if (pass != DCFP_CONV_WGRAD || check_desc(d) != DCFP_OK) return 0;

@@ -14,6 +14,44 @@ from ._lib import ConvDesc, check
 
 _ws_cache = {}
 
+# ---- optional per-launch timing (bench.py's roofline leg): when a list is installed, every
+# conv / BN C-ABI call is bracketed by events on the stream it is launched on.
+_PROFILE = None
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop():
+    """Returns [(kind, key, algorithmic_work, milliseconds)] and disables timing."""
+    global _PROFILE
+    recs, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    return [(k, key, work, s.elapsed_time(e)) for (k, key, work, s, e) in (recs or [])]
+
+
+def _timed(kind, key, work, fn):
+    if _PROFILE is None:
+        return fn()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _PROFILE.append((kind, key, work, s, e))
+    return r
+
+
+def conv_kernel_name(d, which):
+    buf = C.create_string_buffer(64)
+    n = _lib.lib().dcfp_conv2d_kernel_name(C.byref(d), which, buf, 64)
+    return buf.value.decode() if n > 0 else "?"
+
+
+def _conv_flops(d):
+    return 2.0 * d.N * d.Cout * d.Hout * d.Wout * d.Cin * d.KH * d.KW
+
 
 def _require(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -73,8 +111,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1):
     y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
     if bias is not None:
         _require(bias, "bias"); bias = bias.contiguous()
-    check(_lib.lib().dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), 0, _stream()),
-          "conv2d_fwd")
+    _timed("conv_fwd", d, _conv_flops(d), lambda: check(
+        _lib.lib().dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), 0, _stream()),
+        "conv2d_fwd"))
     return y
 
 
@@ -84,8 +123,9 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil):
     d = _desc(xshape, w.shape, stride, pad, dil)
     dy, ns = _batch_strided(dy)
     dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
-    check(_lib.lib().dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), 0, _stream()),
-          "conv2d_dgrad")
+    _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
+        _lib.lib().dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), 0, _stream()),
+        "conv2d_dgrad"))
     return dx
 
 
@@ -99,8 +139,9 @@ def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False):
     ws = _workspace("wgrad", nbytes, x.device)
     dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
     db = torch.empty((wshape[0],), dtype=torch.float32, device=x.device) if need_bias else None
-    check(L.dcfp_conv2d_wgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(x), _p(dw), _p(db), _p(ws),
-                                       ws.numel(), _stream()), "conv2d_wgrad")
+    _timed("conv_wgrad", d, _conv_flops(d), lambda: check(
+        L.dcfp_conv2d_wgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(x), _p(dw), _p(db), _p(ws),
+                                     ws.numel(), _stream()), "conv2d_wgrad"))
     return dw, db
 
 
@@ -140,8 +181,9 @@ def bn_stats(x):
     ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
     mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
     var = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    check(L.dcfp_bn_stats_f32(_p(x), ns, N, Cc, H * W, _p(mean), _p(var), _p(ws), ws.numel(), _stream()),
-          "bn_stats")
+    _timed("bn_stats", None, 4.0 * x.numel(), lambda: check(
+        L.dcfp_bn_stats_f32(_p(x), ns, N, Cc, H * W, _p(mean), _p(var), _p(ws), ws.numel(), _stream()),
+        "bn_stats"))
     return mean, var
 
 
@@ -151,9 +193,11 @@ def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
     if residual is not None:
         residual = residual.contiguous()
     y = torch.empty_like(x)
-    check(_lib.lib().dcfp_bn_apply_f32(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps),
-                                       _p(residual), int(relu), _p(y), 0, N, Cc, H * W, _stream()),
-          "bn_apply")
+    nbytes = (8.0 + (4.0 if residual is not None else 0.0)) * x.numel()
+    _timed("bn_apply", None, nbytes, lambda: check(
+        _lib.lib().dcfp_bn_apply_f32(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps),
+                                     _p(residual), int(relu), _p(y), 0, N, Cc, H * W, _stream()),
+        "bn_apply"))
     return y
 
 
@@ -164,9 +208,10 @@ def bn_bwd_reduce(dy, x, y, mean, relu):
     ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
     s1 = torch.empty(Cc, dtype=torch.float32, device=x.device)
     s2 = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    check(L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean), int(relu),
-                                   N, Cc, H * W, _p(s1), _p(s2), _p(ws), ws.numel(), _stream()),
-          "bn_bwd_reduce")
+    _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu else 0.0)) * x.numel(), lambda: check(
+        L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean), int(relu),
+                                 N, Cc, H * W, _p(s1), _p(s2), _p(ws), ws.numel(), _stream()),
+        "bn_bwd_reduce"))
     return s1, s2
 
 
@@ -175,10 +220,12 @@ def bn_bwd_apply(dy, x, y, mean, var, gamma, eps, s1, s2, count, relu, want_resi
     dy, dns = _batch_strided(dy)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual else None
-    check(_lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean),
-                                           _p(var), _p(gamma), float(eps), _p(s1), _p(s2), float(count),
-                                           int(relu), _p(dx), _p(dres), N, Cc, H * W, _stream()),
-          "bn_bwd_apply")
+    nbytes = (12.0 + (4.0 if relu else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
+    _timed("bn_bwd_apply", None, nbytes, lambda: check(
+        _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean),
+                                         _p(var), _p(gamma), float(eps), _p(s1), _p(s2), float(count),
+                                         int(relu), _p(dx), _p(dres), N, Cc, H * W, _stream()),
+        "bn_bwd_apply"))
     return dx, dres
 
 

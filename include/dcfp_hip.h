@@ -55,6 +55,12 @@ enum { DCFP_CONV_FWD = 0, DCFP_CONV_DGRAD = 1, DCFP_CONV_WGRAD = 2 };
 /* Bytes of workspace a pass needs (0 for fwd/dgrad; split-K slabs for wgrad). */
 size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass);
 
+/* Name of the kernel instance a pass dispatches for this descriptor, e.g.
+ * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the
+ * string rocprofv3 shows (demangled) for the launch; used by bench.py to label rooflines.
+ * Returns the length written (excluding NUL), or <0 on a bad descriptor. */
+int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_len);
+
 /* y = conv(x, w) (+ bias[co] when bias != NULL).  y_nstride: batch stride of y in
  * elements (0 => Cout*Hout*Wout), lets a branch write into a channel slice of a
  * wider tensor (ASPP concat, aspp.py:77). */
