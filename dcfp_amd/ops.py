@@ -238,6 +238,30 @@ def _sync_group(group):
     return g if g is not None else dist.group.WORLD
 
 
+def sync_bn_stats(mean, var, count, group):
+    """SyncBatchNorm forward exchange (engine.py:65): ONE all_gather of [mean, var, count]
+    (2C+1 floats per rank), then the pooled mean / biased variance over all ranks' pixels
+    (parallel-variance combination), identical on every rank."""
+    Cc = mean.numel()
+    world = dist.get_world_size(group)
+    local = torch.cat([mean, var, torch.tensor([float(count)], device=mean.device, dtype=mean.dtype)])
+    allv = torch.empty(world, local.numel(), device=mean.device, dtype=mean.dtype)
+    dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group)
+    means, vars_, counts = allv[:, :Cc], allv[:, Cc:2 * Cc], allv[:, 2 * Cc:]
+    total = counts.sum()
+    gmean = (means * counts).sum(0) / total
+    gvar = ((vars_ + (means - gmean) ** 2) * counts).sum(0) / total
+    return gmean.contiguous(), gvar.contiguous(), float(total.item())
+
+
+def sync_bn_bwd_sums(s1, s2, group):
+    """SyncBatchNorm backward exchange: ONE all_reduce(SUM) of [sum g, sum g*(x-mean)] (2C floats)."""
+    Cc = s1.numel()
+    both = torch.cat([s1, s2])
+    dist.all_reduce(both, group=group)
+    return both[:Cc].contiguous(), both[Cc:].contiguous()
+
+
 class BatchNormActFn(torch.autograd.Function):
     """y = act(BN(x) [+ residual]) with batch statistics (training) or running statistics
     (eval).  Mirrors nn.BatchNorm2d + nn.ReLU(inplace) (+ the Bottleneck residual add,
@@ -256,16 +280,7 @@ class BatchNormActFn(torch.autograd.Function):
         if training:
             mean, var = bn_stats(x)
             if group is not None:
-                # all_gather of [mean, var, count] (2C+1 floats), Chan-combined on every rank
-                world = dist.get_world_size(group)
-                local = torch.cat([mean, var, torch.tensor([count], device=x.device)])
-                allv = torch.empty(world, local.numel(), device=x.device)
-                dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group)
-                means, vars_, counts = allv[:, :Cc], allv[:, Cc:2 * Cc], allv[:, 2 * Cc:]
-                total = counts.sum()
-                gmean = (means * counts).sum(0) / total
-                gvar = ((vars_ + (means - gmean) ** 2) * counts).sum(0) / total
-                mean, var, count = gmean.contiguous(), gvar.contiguous(), float(total.item())
+                mean, var, count = sync_bn_stats(mean, var, count, group)
             if running_mean is not None and momentum is not None:
                 with torch.no_grad():
                     unbiased = var * (count / max(count - 1.0, 1.0))
@@ -288,10 +303,7 @@ class BatchNormActFn(torch.autograd.Function):
         dbeta = s1
         if training:
             if group is not None:
-                both = torch.cat([s1, s2])
-                dist.all_reduce(both, group=group)
-                Cc = s1.numel()
-                r1, r2 = both[:Cc].contiguous(), both[Cc:].contiguous()
+                r1, r2 = sync_bn_bwd_sums(s1, s2, group)
             else:
                 r1, r2 = s1, s2
         else:  # running statistics are constants: dx = g * gamma * istd

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI shared library loads and exports every entry point include/dcfp_hip.h
+declares (no compute calls without a GPU), and the ctypes table mirrors the header."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dcfp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcfp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_header_symbols():
+    from dcfp_amd import _lib
+    path = _lib.LIB_PATH
+    if not os.path.exists(path):
+        _lib.build()
+    h = ctypes.CDLL(path)
+    names = header_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(h, n), n
+    assert sorted(_lib.SIGNATURES.keys()) == names
+    assert h.dcfp_abi_version() == 1
+
+
+def test_descriptor_errors_do_not_need_a_gpu():
+    """Bad descriptors are rejected on the host side with the documented negative codes."""
+    from dcfp_amd import _lib
+    L = _lib.lib()
+    d = _lib.ConvDesc(1, 8, 8, 8, 8, 5, 5, 1, 2, 1, 8, 8)          # 5x5 kernel: unsupported
+    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None) == -2
+    d = _lib.ConvDesc(1, 8, 8, 8, 8, 3, 3, 1, 1, 1, 7, 8)          # wrong Hout
+    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None) == -1
+    assert L.dcfp_bn_stats_f32(None, 0, 1, 1, 1, None, None, None, 0, None) == -1
+    assert L.dcfp_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
+
+
+def test_product_has_no_cpu_path():
+    import pytest
+    import torch
+    from dcfp_amd import networks, ops
+    m = networks.simple.Seg_Model(backbone="resnet50", backbone_para={"pretrained": False}, num_classes=19)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 3, 32, 32))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, 1)
+
+
+def test_oracle_not_imported_by_product():
+    """Nothing under dcfp_amd/ may import, call or link anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dcfp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
