@@ -44,8 +44,8 @@ SIGNATURES = {
     "dcfp_abi_version": (_I, []),
     "dcfp_conv2d_workspace_bytes": (_Z, [_D, _I]),
     "dcfp_conv2d_kernel_name": (_I, [_D, _I, C.c_char_p, _I]),
-    "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P]),
-    "dcfp_conv2d_dgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _I, _P]),
+    "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P, _Z, _P]),
+    "dcfp_conv2d_dgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _I, _P, _Z, _P]),
     "dcfp_conv2d_wgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _P, _P, _Z, _P]),
     "dcfp_bn_workspace_bytes": (_Z, [_I, _I, _I]),
     "dcfp_bn_stats_f32": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),

@@ -19,6 +19,7 @@
 // staging instructions per lane, which is why plain predicated dword loads suffice.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -319,8 +320,28 @@ int check_desc(const DcfpConvDesc* d) {
 
 extern "C" int dcfp_abi_version(void) { return 1; }
 
-// implemented in conv_wgrad.hip
+// implemented in conv_wgrad.hip / conv_igemm2.hip
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len);
+size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd);
+const char* dcfp_igemm2_cfg_args(int M, long long px, int sd);
+int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
+                    const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
+                    int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
+                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+// DCFP_IGEMM_V1=1 keeps the first-generation kernel (A/B comparisons in one process).
+static bool use_v1() {
+    static const bool v = getenv("DCFP_IGEMM_V1") != nullptr;
+    return v;
+}
+
+extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
+    if (check_desc(d) != DCFP_OK || use_v1()) return 0;
+    const int T = d->KH * d->KW;
+    if (pass == DCFP_CONV_FWD)
+        return dcfp_igemm2_workspace_bytes(T, d->Cout, d->Cin, (long long)d->N * d->Hout * d->Wout, 1);
+    return dcfp_igemm2_workspace_bytes(T, d->Cin, d->Cout, (long long)d->N * d->H * d->W, d->stride);
+}
 
 extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_len) {
     int rc = check_desc(d);
@@ -331,16 +352,25 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     p.N = d->N;
     if (pass == DCFP_CONV_FWD) { p.M = d->Cout; p.P = d->Hout * d->Wout; p.sd = 1; }
     else { p.M = d->Cin; p.P = d->H * d->W; p.sd = d->stride; }
+    if (!use_v1())
+        return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW,
+                        dcfp_igemm2_cfg_args(p.M, (long long)p.N * p.P, p.sd));
     return snprintf(buf, buf_len, "igemm_kernel<%d,%s>", d->KH * d->KW, cfg_args(pick_cfg(p)));
 }
 
 extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                                         const float* bias, float* y, int64_t y_nstride,
+                                        void* workspace, size_t workspace_bytes,
                                         dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (!use_v1())
+        return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
+                               y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
+                               d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
+                               d->dil, 0, workspace, workspace_bytes, dcfp_s(stream));
     IgemmParams p;
     p.in = x; p.wgt = w; p.bias = bias; p.out = y;
     p.in_nstride = (long long)d->Cin * d->H * d->W;
@@ -357,11 +387,17 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
 
 extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy,
                                           int64_t dy_nstride, const float* w, float* dx,
-                                          int accumulate, dcfp_stream_t stream) {
+                                          int accumulate, void* workspace, size_t workspace_bytes,
+                                          dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !w || !dx) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (!use_v1())
+        return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
+                               T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
+                               d->Cout, T, d->Hout, d->Wout, d->H, d->W, 1, d->stride, d->pad, -d->dil,
+                               accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream));
     IgemmParams p;
     p.in = dy; p.wgt = w; p.bias = nullptr; p.out = dx;
     p.in_nstride = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout;

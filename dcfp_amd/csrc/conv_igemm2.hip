@@ -1,0 +1,386 @@
+// conv_igemm2.hip — second-generation implicit-GEMM conv forward / data-gradient kernel
+// (fp32 MFMA, NCHW).  Same math and tiling as conv_igemm.hip (see its header); what changed is
+// everything AROUND the MFMAs, after the round-1 profile showed the matrix pipe idle ~45 % of
+// the time while one wave per SIMD issued staging code and MFMAs back to back:
+//
+//  * K is ordered TAP-MAJOR (k = tap*C + c): a 16-deep K-step touches ONE tap, so the
+//    per-pixel source offsets / border predicates are computed once per tap, and a row of the
+//    B tile is just `+ c*H*W`.  Staging costs ~1 VALU per load instead of ~10.
+//  * the A operand comes from a pre-permuted, zero-padded copy of the weights
+//    Wp[tap][c][m] (m contiguous, built by permute_weights_kernel in the same call: <= 19 MB,
+//    microseconds): 16-byte coalesced loads, 16-byte LDS stores, no predication at all.
+//  * MFMA operand fragments are double-buffered in registers (the ds_read for step kk+1 is
+//    issued before the 16 MFMAs of step kk), and the next tile's global loads / LDS stores are
+//    spread over the eight 16-MFMA slots of a K-step instead of forming one serial block.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+constexpr unsigned kOob = 0x80000000u;
+
+struct Igemm2Params {
+    const float* in;
+    const float* wp;    // permuted weights [T][CkP][Mpad]
+    const float* bias;
+    float* out;
+    long long in_nstride, out_nstride;
+    int N, M, Mpad, Ck, CkP;
+    int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
+    int sn, sd, off0, offstep;
+    int accumulate, vec_store;
+};
+
+// Wp[t][c][m] = W[m*sAm + c*sAc + t]  (zero for c >= Ck or m >= M)
+__global__ void __launch_bounds__(256)
+permute_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int T, int Ck, int CkP,
+                       int M, int Mpad, int sAm, int sAc) {
+    const long long total = (long long)T * CkP * Mpad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (long long)gridDim.x * 256) {
+        const int m = (int)(i % Mpad);
+        const long long r = i / Mpad;
+        const int c = (int)(r % CkP);
+        const int t = (int)(r / CkP);
+        float v = 0.f;
+        if (m < M && c < Ck) v = w[(long long)m * sAm + (long long)c * sAc + t];
+        wp[i] = v;
+    }
+}
+
+// compile-time loop: every index is a constant expression, so register arrays stay in registers
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int T>
+struct Frag;
+template <>
+struct Frag<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+};
+template <>
+struct Frag<2> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[2]) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        f[0] = v.x; f[1] = v.y;
+    }
+};
+template <>
+struct Frag<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[1]) { f[0] = p[0]; }
+};
+
+template <int TAPS, int TM, int TN, int WM, int WN, bool SD>
+__global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    // A: thread -> (4 consecutive m, rows ay + AROWS*j)
+    constexpr int AX = BM / 4;                       // threads across a row
+    constexpr int AROWS = (NT / AX) < BK ? (NT / AX) : BK;   // rows per pass
+    constexpr int APASS = BK / AROWS;
+    // B: thread -> (4 consecutive pixels, rows ty + TY*q)
+    constexpr int TX = BN / 4, TY = NT / TX, RPT = BK / TY;
+    static_assert(APASS >= 1 && APASS * AROWS == BK, "A loader shape");
+    static_assert(TY >= 1 && RPT >= 1 && TY * RPT == BK, "B loader shape");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
+
+    const int group = 8 * p.tiles_m;
+    const int g = blockIdx.x / group, local = blockIdx.x - g * group;
+    const int nt = g * 8 + (local & 7);
+    const int mt = local >> 3;
+    if (nt >= p.tiles_n_total) return;
+    const int img = nt / p.tiles_per_img;
+    const int p0 = (nt - img * p.tiles_per_img) * BN;
+    const int m0 = mt * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- A loader
+    const int ax = tid % AX, ay = tid / AX;
+    const bool a_on = ay < BK;   // BM == 32: only half of the threads stage A
+    const float* a_src = p.wp + m0 + 4 * ax;
+
+    // ---- B loader
+    const int tx = tid % TX, ty = tid / TX;
+    int bh[4], bw[4];
+    bool pv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int pp = p0 + 4 * tx + e;
+        pv[e] = pp < p.P;
+        const int oh = pp / p.Wo;
+        const int ow = pp - oh * p.Wo;
+        bh[e] = oh * p.sn;
+        bw[e] = ow * p.sn;
+    }
+    const int HiWi = p.Hi * p.Wi;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in + (long long)img * p.in_nstride), 0, p.Ck * HiWi * 4, 0x00020000);
+
+    const int ksteps_per_tap = p.CkP / BK;
+    const int nk = TAPS * ksteps_per_tap;
+
+    unsigned boff[4];            // per-pixel byte offsets of the current tap (kOob when padded)
+    f32x4 areg[APASS];
+    float breg[RPT][4];
+
+    auto set_tap = [&](int t) {
+        const int kh = (TAPS == 9) ? t / 3 : 0;
+        const int kw = (TAPS == 9) ? t - kh * 3 : 0;
+        const int offh = p.off0 + kh * p.offstep;
+        const int offw = p.off0 + kw * p.offstep;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int hh = bh[e] + offh, ww = bw[e] + offw;
+            bool ok = pv[e] && hh >= 0 && ww >= 0;
+            if (SD) {
+                ok = ok && (hh % p.sd == 0) && (ww % p.sd == 0);
+                hh /= p.sd;
+                ww /= p.sd;
+            }
+            ok = ok && hh < p.Hi && ww < p.Wi;
+            boff[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+        }
+    };
+    // quarter PART (0..3) of the staging loads of K-step kt
+    auto load_part = [&](int kt, auto part_) {
+        constexpr int PART = decltype(part_)::value;
+        const int t = kt / ksteps_per_tap;
+        const int c0 = (kt - t * ksteps_per_tap) * BK;
+        if (PART == 0 && c0 == 0) set_tap(t);
+        static_for<0, APASS>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr ((j & 3) == PART) {
+                if (a_on)
+                    areg[j] = *reinterpret_cast<const f32x4*>(
+                        a_src + (long long)(t * p.CkP + c0 + ay + AROWS * j) * p.Mpad);
+            }
+        });
+        static_for<0, RPT>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            if constexpr ((q & 3) == PART) {
+                int c = c0 + ty + TY * q;
+                c = c < p.Ck ? c : p.Ck - 1;        // rows past Ck meet zero rows of Wp
+                const unsigned coff = (unsigned)(c * HiWi) * 4u;
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    breg[q][e] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, boff[e] + coff, 0, 0));
+                });
+            }
+        });
+    };
+    auto store_a = [&](int buf) {
+        float* a = As + buf * (BK * BM);
+        static_for<0, APASS>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if (a_on) *reinterpret_cast<f32x4*>(a + (ay + AROWS * j) * BM + 4 * ax) = areg[j];
+        });
+    };
+    auto store_b = [&](int buf) {
+        float* b = Bs + buf * (BK * BN);
+        static_for<0, RPT>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            f32x4 v = {breg[q][0], breg[q][1], breg[q][2], breg[q][3]};
+            *reinterpret_cast<f32x4*>(b + (ty + TY * q) * BN + 4 * tx) = v;
+        });
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    static_for<0, 4>([&](auto part_) { load_part(0, part_); });
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+
+    const int a_off = wm * (TM * 32) + TM * l31;
+    const int b_off = wn * (TN * 32) + TN * l31;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        const float* a = As + cur * (BK * BM) + a_off + lhi * BM;
+        const float* b = Bs + cur * (BK * BN) + b_off + lhi * BN;
+        float af[2][TM], bf[2][TN];
+        Frag<TM>::ld(a, af[0]);
+        Frag<TN>::ld(b, bf[0]);
+        static_for<0, BK / 2>([&](auto kk_) {
+            constexpr int kk = decltype(kk_)::value;
+            constexpr int fc = kk & 1;
+            if constexpr (kk + 1 < BK / 2) {   // operands of the next 16 MFMAs
+                Frag<TM>::ld(a + (2 * kk + 2) * BM, af[fc ^ 1]);
+                Frag<TN>::ld(b + (2 * kk + 2) * BN, bf[fc ^ 1]);
+            }
+            if (more) {
+                if constexpr (kk < 4) load_part(kt + 1, std::integral_constant<int, kk>{});
+                if constexpr (kk == 6) store_a(cur ^ 1);
+                if constexpr (kk == 7) store_b(cur ^ 1);
+            }
+            static_for<0, TM>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                static_for<0, TN>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fc][i], bf[fc][j], acc[i][j], 0, 0, 0);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    }
+
+    // ---- epilogue (the opaque asm keeps its 64 row pointers from being hoisted above the K loop)
+    float* o_img = p.out + (long long)img * p.out_nstride;
+    int pix = p0 + wn * (TN * 32) + TN * l31;
+    asm volatile("" : "+v"(pix));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int m = m0 + wm * (TM * 32) + TM * row + i;
+            if (m >= p.M) continue;
+            float v[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+            if (p.bias) {
+                const float bsv = p.bias[m];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] += bsv;
+            }
+            float* dst = o_img + (long long)m * p.P + pix;
+            if (TN == 4 && p.vec_store && pix + 3 < p.P) {
+                float4 o = make_float4(v[0], v[1], v[TN > 2 ? 2 : 0], v[TN > 3 ? 3 : 0]);
+                if (p.accumulate) {
+                    const float4 old = *reinterpret_cast<const float4*>(dst);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (pix + j < p.P) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+                }
+            }
+        }
+    }
+}
+
+template <int TAPS, int TM, int TN, int WM, int WN, bool SD = false>
+int launch_cfg(Igemm2Params& p, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    const long long groups = ((long long)p.tiles_n_total + 7) / 8;
+    const long long blocks = groups * 8 * p.tiles_m;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
+    auto kern = igemm2_kernel<TAPS, TM, TN, WM, WN, SD>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, stream, p);
+    DCFP_RETURN_LAUNCH();
+}
+
+struct TileCfg { int bm, bn, id; };
+// 0: 32x512  1: 64x512  2: 128x256  3: 128x128  4: 256x256  5: 128x256 strided-dgrad
+TileCfg pick_cfg(int M, long long px, int sd) {
+    if (sd > 1) return {128, 256, 5};
+    auto blocks = [&](int bm, int bn) { return ((long long)(M + bm - 1) / bm) * ((px + bn - 1) / bn); };
+    if (M <= 32) return {32, 512, 0};
+    if (M <= 64) return {64, 512, 1};
+    if (M <= 128) return blocks(128, 256) >= 192 ? TileCfg{128, 256, 2} : TileCfg{128, 128, 3};
+    if (blocks(256, 256) >= 192) return {256, 256, 4};
+    if (blocks(128, 256) >= 192) return {128, 256, 2};
+    return {128, 128, 3};
+}
+
+template <int TAPS>
+int launch_taps(Igemm2Params& p, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_cfg<TAPS, 1, 4, 1, 4>(p, stream);
+        case 1: return launch_cfg<TAPS, 2, 4, 1, 4>(p, stream);
+        case 2: return launch_cfg<TAPS, 2, 4, 2, 2>(p, stream);
+        case 3: return launch_cfg<TAPS, 2, 2, 2, 2>(p, stream);
+        case 4: return launch_cfg<TAPS, 4, 4, 2, 2>(p, stream);
+        default: return launch_cfg<TAPS, 2, 4, 2, 2, true>(p, stream);
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+// ---- entry points used by conv_igemm.hip's C-ABI functions
+size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
+    const TileCfg c = pick_cfg(M, px, sd);
+    return (size_t)T * round_up(Ck, BK) * round_up(M, c.bm) * sizeof(float);
+}
+
+const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
+    switch (pick_cfg(M, px, sd).id) {
+        case 0: return "1,4,1,4,0";
+        case 1: return "2,4,1,4,0";
+        case 2: return "2,4,2,2,0";
+        case 3: return "2,2,2,2,0";
+        case 4: return "4,4,2,2,0";
+        default: return "2,4,2,2,1";
+    }
+}
+
+// in: B-source tensor; w: reference-layout weights; (sAm, sAc): A strides in w
+int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
+                    const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
+                    int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
+                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const long long px = (long long)N * Ho * Wo;
+    const TileCfg c = pick_cfg(M, px, sd);
+    Igemm2Params p;
+    p.in = in; p.bias = bias; p.out = out;
+    p.in_nstride = in_nstride; p.out_nstride = out_nstride;
+    p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, BK); p.Mpad = round_up(M, c.bm);
+    p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
+    p.tiles_per_img = (p.P + c.bn - 1) / c.bn;
+    p.tiles_n_total = p.tiles_per_img * N;
+    p.tiles_m = p.Mpad / c.bm;
+    p.sn = sn; p.sd = sd; p.off0 = off0; p.offstep = offstep;
+    p.accumulate = accumulate;
+    p.vec_store = (p.P % 4 == 0) && (out_nstride % 4 == 0) && dcfp_aligned16(out);
+    const size_t need = (size_t)T * p.CkP * p.Mpad * sizeof(float);
+    if (!workspace || workspace_bytes < need || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
+    float* wp = static_cast<float*>(workspace);
+    p.wp = wp;
+    {
+        const long long total = (long long)T * p.CkP * p.Mpad;
+        long long b = (total + 255) / 256;
+        if (b > 2048) b = 2048;
+        hipLaunchKernelGGL(permute_weights_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, wp, T,
+                           Ck, p.CkP, M, p.Mpad, sAm, sAc);
+    }
+    return T == 1 ? launch_taps<1>(p, c.id, stream) : launch_taps<9>(p, c.id, stream);
+}

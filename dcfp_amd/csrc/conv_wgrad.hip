@@ -335,7 +335,10 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     return snprintf(buf, buf_len, "wgrad_kernel<%d,%s>", d->KH * d->KW, args);
 }
 
+extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
+
 extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
+    if (pass == DCFP_CONV_FWD || pass == DCFP_CONV_DGRAD) return dcfp_conv2d_fwd_dgrad_workspace_bytes_(d, pass);
     if (pass != DCFP_CONV_WGRAD || check_desc(d) != DCFP_OK) return 0;
     const Plan pl = make_plan(d);
     if (pl.splits <= 1) return 0;

@@ -111,9 +111,11 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1):
     y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
     if bias is not None:
         _require(bias, "bias"); bias = bias.contiguous()
+    L = _lib.lib()
+    ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), x.device)
     _timed("conv_fwd", d, _conv_flops(d), lambda: check(
-        _lib.lib().dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), 0, _stream()),
-        "conv2d_fwd"))
+        L.dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), 0, _p(ws), ws.numel(),
+                                   _stream()), "conv2d_fwd"))
     return y
 
 
@@ -123,9 +125,11 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil):
     d = _desc(xshape, w.shape, stride, pad, dil)
     dy, ns = _batch_strided(dy)
     dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+    L = _lib.lib()
+    ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_DGRAD), dy.device)
     _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
-        _lib.lib().dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), 0, _stream()),
-        "conv2d_dgrad"))
+        L.dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), 0, _p(ws), ws.numel(),
+                                     _stream()), "conv2d_dgrad"))
     return dx
 
 

@@ -52,7 +52,8 @@ typedef struct DcfpConvDesc {
 
 enum { DCFP_CONV_FWD = 0, DCFP_CONV_DGRAD = 1, DCFP_CONV_WGRAD = 2 };
 
-/* Bytes of workspace a pass needs (0 for fwd/dgrad; split-K slabs for wgrad). */
+/* Bytes of workspace a pass needs: fwd/dgrad — the permuted, zero-padded weight copy
+ * Wp[tap][c][m] the kernel streams its A operand from; wgrad — the split-K slabs. */
 size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass);
 
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
@@ -66,11 +67,13 @@ int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_
  * wider tensor (ASPP concat, aspp.py:77). */
 int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                              const float* bias, float* y, int64_t y_nstride,
+                             void* workspace, size_t workspace_bytes,
                              dcfp_stream_t stream);
 /* dx = conv_transpose(dy, w); accumulate != 0 => dx += (fan-out gradients).
  * dy_nstride: batch stride of dy in elements (0 => dense). */
 int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
                                const float* w, float* dx, int accumulate,
+                               void* workspace, size_t workspace_bytes,
                                dcfp_stream_t stream);
 /* dw[co,ci,kh,kw] = sum_{n,p} dy[n,co,p] * x[n,ci,src(p,kh,kw)]; deterministic
  * two-stage split-K (no float atomics).  db (nullable) = sum_{n,p} dy. */

@@ -32,9 +32,9 @@ def test_descriptor_errors_do_not_need_a_gpu():
     from dcfp_amd import _lib
     L = _lib.lib()
     d = _lib.ConvDesc(1, 8, 8, 8, 8, 5, 5, 1, 2, 1, 8, 8)          # 5x5 kernel: unsupported
-    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None) == -2
+    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None, 0, None) == -2
     d = _lib.ConvDesc(1, 8, 8, 8, 8, 3, 3, 1, 1, 1, 7, 8)          # wrong Hout
-    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None) == -1
+    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None, 0, None) == -1
     assert L.dcfp_bn_stats_f32(None, 0, 1, 1, 1, None, None, None, 0, None) == -1
     assert L.dcfp_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
 

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the conv C-ABI entry points on the FLOP-dominant shapes of
+DeepLabv3-R101 @ 4x3x1024x2048.  Prints TFLOP/s per pass; variants
+of a kernel are A/B-ed in ONE process via DCFP_* environment switches read by the library."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from dcfp_amd import ops  # noqa: E402
+
+SHAPES = {
+    # name: (N, Cin, H, W, Cout, k, stride, pad, dil)
+    "l3c2_3x3d2": (4, 256, 128, 256, 256, 3, 1, 2, 2),
+    "l3c3_1x1": (4, 256, 128, 256, 1024, 1, 1, 0, 1),
+    "l3c1_1x1": (4, 1024, 128, 256, 256, 1, 1, 0, 1),
+    "aspp_3x3d12": (4, 2048, 128, 256, 256, 3, 1, 12, 12),
+    "ds_3x3": (4, 1024, 128, 256, 512, 3, 1, 1, 1),
+    "l4c2_3x3d4": (4, 512, 128, 256, 512, 3, 1, 4, 4),
+    "l4c3_1x1": (4, 512, 128, 256, 2048, 1, 1, 0, 1),
+    "l4c1_1x1": (4, 2048, 128, 256, 512, 1, 1, 0, 1),
+    "stem2_3x3": (4, 64, 512, 1024, 64, 3, 1, 1, 1),
+    "stem3_3x3": (4, 64, 512, 1024, 128, 3, 1, 1, 1),
+    "l1c2_3x3": (4, 64, 256, 512, 64, 3, 1, 1, 1),
+    "l2c2_3x3": (4, 128, 128, 256, 128, 3, 1, 1, 1),
+}
+
+
+def bench(fn, iters):
+    fn(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="l3c2_3x3d2,l3c3_1x1,l3c1_1x1,aspp_3x3d12,ds_3x3")
+    ap.add_argument("--passes", default="fwd,dgrad,wgrad")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--check", action="store_true", help="compare with torch CPU conv on a slice")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for name in args.shapes.split(","):
+        N, Cin, H, W, Cout, k, s, p, d = SHAPES[name]
+        x = torch.randn(N, Cin, H, W, device=dev)
+        w = torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5
+        y = ops.conv2d_fwd(x, w, None, s, p, d)
+        dy = torch.randn_like(y)
+        flops = 2.0 * N * Cout * y.shape[2] * y.shape[3] * Cin * k * k
+        res = {}
+        if "fwd" in args.passes:
+            res["fwd"] = bench(lambda: ops.conv2d_fwd(x, w, None, s, p, d), args.iters)
+        if "dgrad" in args.passes:
+            res["dgrad"] = bench(lambda: ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d), args.iters)
+        if "wgrad" in args.passes:
+            res["wgrad"] = bench(lambda: ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, d), args.iters)
+        line = f"{name:14s} " + "  ".join(f"{k_}: {v:7.3f} ms {flops / v / 1e9:6.1f} TF" for k_, v in res.items())
+        print(line, flush=True)
+        if args.check:
+            xs, ws = x[:1, :, :32].cpu().double(), w.cpu().double()
+            ref = torch.nn.functional.conv2d(xs, ws, None, s, p, d)
+            got = ops.conv2d_fwd(x[:1, :, :32].contiguous(), w, None, s, p, d).cpu().double()
+            print("   fwd rel err", ((got - ref).norm() / ref.norm()).item())
+
+
+if __name__ == "__main__":
+    main()
