@@ -15,6 +15,8 @@
 // 16-byte read per lane feeds FOUR consecutive k-steps of a 32x32x2 MFMA tile.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -230,6 +232,295 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p
     }
 }
 
+// compile-time loop (all indices constant expressions: register arrays stay in registers)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((vector_size(16)));
+
+// Second-generation wgrad kernel: same tiling / LDS layout / split-K as wgrad_kernel, but
+//  * MFMA operand fragments are double-buffered in registers (reads for the next 64 MFMAs are
+//    issued before the current 64),
+//  * the next K-step's staging (pixel coordinates tracked incrementally instead of two integer
+//    divisions per step, 32 buffer loads, 8 LDS stores) is spread over the eight 16-MFMA slots
+//    of a K-step instead of running as one serial block in front of the MFMAs,
+//  * rows past M / Nn are clamped instead of predicated (they only feed discarded outputs).
+template <int TAPS, int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) wgrad2_kernel(const WgradParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    constexpr int ROWS = NT / 4;
+    constexpr int PA = BM / ROWS, PB = BN / ROWS;
+    static_assert(PA >= 1 && PB >= 1 && PA * ROWS == BM && PB * ROWS == BN, "loader shape");
+    static_assert(PA <= 4 && PB <= 4, "slot schedule assumes <= 4 row passes per operand");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [2][BM][BKP]
+    float* Bs = smem + 2 * BM * BKP;      // [2][BN][BKP]
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / tiles;
+    const int tile = blockIdx.x - split * tiles;
+    const int mt = tile / p.tiles_n, ntile = tile - mt * p.tiles_n;
+    const int m0 = mt * BM, n0 = ntile * BN;
+    const int kbeg = split * p.kchunk;
+    int kend = kbeg + p.kchunk;
+    if (kend > p.Kpix || kend < kbeg) kend = p.Kpix;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // staging map: 16 consecutive lanes = 16 consecutive rows at one pixel quad, so the eight
+    // lanes of a ds_write_b128 group hit 32 distinct banks with the 20-float row pitch
+    const int kx = lane >> 4, rrow = wid * 16 + (lane & 15);
+
+    const int img0 = kbeg / p.P;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy + (long long)img0 * p.dy_nstride), 0, kMaxRecords, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (long long)img0 * p.x_nstride), 0, kMaxRecords, 0x00020000);
+    const int dyn = (int)p.dy_nstride, xn = (int)p.x_nstride;
+
+    // ---- per-thread rows (fixed over the K loop); out-of-range rows are clamped: they only
+    // feed output rows / columns that are never stored
+    int a_off[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        int m = m0 + rrow + ROWS * j;
+        m = m < p.M ? m : p.M - 1;
+        a_off[j] = m * p.P;
+    }
+    int b_coff[PB], b_dh[PB], b_dw[PB];
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        int nn = n0 + rrow + ROWS * j;
+        nn = nn < p.Nn ? nn : p.Nn - 1;
+        const int ci = nn / TAPS;
+        const int t = nn - ci * TAPS;
+        const int kh = (TAPS == 9) ? t / 3 : 0;
+        const int kw = (TAPS == 9) ? t - kh * 3 : 0;
+        b_dh[j] = kh * p.dil - p.pad;
+        b_dw[j] = kw * p.dil - p.pad;
+        b_coff[j] = ci * HW + b_dh[j] * p.W + b_dw[j];   // channel + tap shift, relative to (ih, iw)
+    }
+
+    // ---- pixel coordinates of this thread's quad, advanced by BK pixels per K-step
+    int c_im, c_oh, c_ow;            // image (relative to img0), output row / col of the quad
+    {
+        const int q0 = kbeg + 4 * kx;
+        const int imabs = q0 / p.P;
+        const int pq = q0 - imabs * p.P;
+        c_im = imabs - img0;
+        c_oh = pq / p.Wo;
+        c_ow = pq - c_oh * p.Wo;
+    }
+    // quad path (Wo % 4 == 0): per-K-step scalars of the quad
+    bool q_ok = false;               // quad inside [kbeg, kend)
+    int q_a = 0, q_x = 0, q_ih = 0, q_iw = 0;   // dy offset, x offset of (ih, iw), ih, iw
+    // generic path: per-element coordinates
+    int img[4], pp[4], ih[4], iw[4];
+    bool qv[4];
+    float areg[PA][4], breg[PB][4];
+
+    auto coords = [&](int kbase) {
+        const int q0 = kbase + 4 * kx;
+        if (p.quad_ok) {
+            q_ok = q0 < kend;        // kchunk % 16 == 0 and Kpix % 4 == 0: a quad is all-or-nothing
+            q_a = c_im * dyn + c_oh * p.Wo + c_ow;
+            q_ih = c_oh * p.stride;
+            q_iw = c_ow * p.stride;
+            q_x = c_im * xn + q_ih * p.W + q_iw;
+            c_ow += BK;
+            while (c_ow >= p.Wo) { c_ow -= p.Wo; ++c_oh; }
+            while (c_oh >= p.Ho) { c_oh -= p.Ho; ++c_im; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = q0 + e;
+                qv[e] = q < kend;
+                const int imabs = q / p.P;
+                const int pq = q - imabs * p.P;
+                const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
+                img[e] = imabs - img0; pp[e] = pq;
+                ih[e] = oh * p.stride; iw[e] = ow * p.stride;
+            }
+        }
+    };
+    auto load_a = [&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j < PA) {
+            if (p.quad_ok) {         // 16-byte aligned quad of dy: one dwordx4
+                const unsigned off = q_ok ? (unsigned)(q_a + a_off[j]) * 4u : kOob;
+                // NOTE: bit-cast the whole vector first — indexing the builtin's integer vector
+                // makes hipcc (ROCm 7.2) shrink the load to ONE dword (wrong results)
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    areg[j][e] = v[e];
+                });
+            } else {
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    const unsigned off = qv[e] ? (unsigned)(img[e] * dyn + a_off[j] + pp[e]) * 4u : kOob;
+                    areg[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off, 0, 0));
+                });
+            }
+        }
+    };
+    auto load_b = [&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j < PB) {
+            if (p.quad_ok && p.stride == 1) {
+                // 4 consecutive input pixels of one row: one (possibly unaligned) dwordx4 when the
+                // row is inside the image and the quad does not cross its left/right edge
+                const int hh = q_ih + b_dh[j], ww = q_iw + b_dw[j];
+                const bool rowok = q_ok && hh >= 0 && hh < p.H;
+                const unsigned base = (unsigned)(q_x + b_coff[j]) * 4u;
+                if (!rowok || (ww >= 0 && ww + 3 < p.W)) {
+                    const f32x4 v = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, rowok ? base : kOob, 0, 0));
+                    static_for<0, 4>([&](auto e_) {
+                        constexpr int e = decltype(e_)::value;
+                        breg[j][e] = v[e];
+                    });
+                } else {
+                    static_for<0, 4>([&](auto e_) {
+                        constexpr int e = decltype(e_)::value;
+                        const bool ok = (ww + e) >= 0 && (ww + e) < p.W;
+                        breg[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            b_rsrc, ok ? base + 4u * e : kOob, 0, 0));
+                    });
+                }
+            } else if (p.quad_ok) {
+                const int hh = q_ih + b_dh[j];
+                const bool rowok = q_ok && hh >= 0 && hh < p.H;
+                const unsigned base = (unsigned)(q_x + b_coff[j]) * 4u;
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    const int ww = q_iw + e * p.stride + b_dw[j];
+                    const bool ok = rowok && ww >= 0 && ww < p.W;
+                    breg[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        b_rsrc, ok ? base + (unsigned)(4 * e * p.stride) : kOob, 0, 0));
+                });
+            } else {
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    const int hh = ih[e] + b_dh[j], ww = iw[e] + b_dw[j];
+                    const bool ok = qv[e] && hh >= 0 && ww >= 0 && hh < p.H && ww < p.W;
+                    const unsigned off = ok ? (unsigned)(img[e] * xn + b_coff[j] + ih[e] * p.W + iw[e]) * 4u : kOob;
+                    breg[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, off, 0, 0));
+                });
+            }
+        }
+    };
+    auto store_a = [&](int buf) {
+        float* a = As + buf * (BM * BKP);
+        static_for<0, PA>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            const f32x4 v = {areg[j][0], areg[j][1], areg[j][2], areg[j][3]};
+            *reinterpret_cast<f32x4*>(a + (rrow + ROWS * j) * BKP + 4 * kx) = v;
+        });
+    };
+    auto store_b = [&](int buf) {
+        float* b = Bs + buf * (BN * BKP);
+        static_for<0, PB>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            const f32x4 v = {breg[j][0], breg[j][1], breg[j][2], breg[j][3]};
+            *reinterpret_cast<f32x4*>(b + (rrow + ROWS * j) * BKP + 4 * kx) = v;
+        });
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        coords(kbeg);
+        static_for<0, 4>([&](auto j_) { load_a(j_); load_b(j_); });
+        store_a(0);
+        store_b(0);
+    }
+    __syncthreads();
+
+    const int a_row = wm * (TM * 32) + l31;
+    const int b_row = wn * (TN * 32) + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        const float* a = As + cur * (BM * BKP) + a_row * BKP + 4 * lhi;
+        const float* b = Bs + cur * (BN * BKP) + b_row * BKP + 4 * lhi;
+        f32x4 af[2][TM], bf[2][TN];
+        static_for<0, TM>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BKP);
+        });
+        static_for<0, TN>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * BKP);
+        });
+        static_for<0, 8>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            constexpr int kq = s / 4, e = s % 4;
+            if constexpr (s == 0) {   // fragments of the second half of this K-step
+                static_for<0, TM>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    af[1][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BKP + 8);
+                });
+                static_for<0, TN>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    bf[1][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * BKP + 8);
+                });
+            }
+            if (more) {
+                if constexpr (s == 0) { coords(kbeg + (kt + 1) * BK); load_a(std::integral_constant<int, 0>{}); load_a(std::integral_constant<int, 1>{}); }
+                if constexpr (s == 1) { load_a(std::integral_constant<int, 2>{}); load_a(std::integral_constant<int, 3>{}); }
+                if constexpr (s >= 2 && s <= 5) load_b(std::integral_constant<int, s - 2>{});
+                if constexpr (s == 6) store_a(cur ^ 1);
+                if constexpr (s == 7) store_b(cur ^ 1);
+            }
+            static_for<0, TM>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                static_for<0, TN>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][i][e], bf[kq][j][e], acc[i][j], 0, 0, 0);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    }
+
+    float* o = p.out + (long long)split * p.M * p.Nn;
+    int ncol = n0 + wn * (TN * 32) + l31;
+    asm volatile("" : "+v"(ncol));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int m = m0 + wm * (TM * 32) + i * 32 + row;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nn = ncol + j * 32;
+                if (nn < p.Nn) o[(long long)m * p.Nn + nn] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // dw[i] = sum_s slab[s][i], s ascending (fixed order).
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int splits) {
@@ -301,11 +592,16 @@ int check_desc(const DcfpConvDesc* d) {
     return DCFP_OK;
 }
 
+static bool wgrad_v1() {
+    static const bool v = getenv("DCFP_WGRAD_V1") != nullptr;
+    return v;
+}
+
 template <int TAPS, int TM, int TN, int WM, int WN>
 int launch_cfg(const WgradParams& p, long long blocks, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
-    auto kern = wgrad_kernel<TAPS, TM, TN, WM, WN>;
+    auto kern = wgrad_v1() ? wgrad_kernel<TAPS, TM, TN, WM, WN> : wgrad2_kernel<TAPS, TM, TN, WM, WN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -332,7 +628,7 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : "2,2,1,1";
-    return snprintf(buf, buf_len, "wgrad_kernel<%d,%s>", d->KH * d->KW, args);
+    return snprintf(buf, buf_len, "%s<%d,%s>", wgrad_v1() ? "wgrad_kernel" : "wgrad2_kernel", d->KH * d->KW, args);
 }
 
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
