@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
     const int nk = TAPS * ksteps_per_tap;
 
     unsigned boff[4];            // per-pixel byte offsets of the current tap (kOob when padded)
+    bool bvec = false;           // the 4 pixels are one contiguous in-image run (or all padding)
     f32x4 areg[APASS];
     float breg[RPT][4];
 
@@ -160,6 +161,10 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
             ok = ok && hh < p.Hi && ww < p.Wi;
             boff[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
         }
+        const bool none = boff[0] == kOob && boff[1] == kOob && boff[2] == kOob && boff[3] == kOob;
+        const bool run = boff[0] != kOob && boff[1] == boff[0] + 4u && boff[2] == boff[0] + 8u &&
+                         boff[3] == boff[0] + 12u;
+        bvec = none || run;
     };
     // quarter PART (0..3) of the staging loads of K-step kt
     auto load_part = [&](int kt, auto part_) {
@@ -181,11 +186,20 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
                 int c = c0 + ty + TY * q;
                 c = c < p.Ck ? c : p.Ck - 1;        // rows past Ck meet zero rows of Wp
                 const unsigned coff = (unsigned)(c * HiWi) * 4u;
-                static_for<0, 4>([&](auto e_) {
-                    constexpr int e = decltype(e_)::value;
-                    breg[q][e] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, boff[e] + coff, 0, 0));
-                });
+                if (bvec) {   // one (possibly unaligned) dwordx4; bit-cast the WHOLE vector (see wgrad)
+                    const f32x4 v = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[0] + coff, 0, 0));
+                    static_for<0, 4>([&](auto e_) {
+                        constexpr int e = decltype(e_)::value;
+                        breg[q][e] = v[e];
+                    });
+                } else {
+                    static_for<0, 4>([&](auto e_) {
+                        constexpr int e = decltype(e_)::value;
+                        breg[q][e] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, boff[e] + coff, 0, 0));
+                    });
+                }
             }
         });
     };
