@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", default="2,256,512", help="n,h,w of the CPU baseline sample")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="wrap in SyncBN+DDP and run the collectives even at world size 1 (rehearsal)")
     args, _ = ap.parse_known_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +171,11 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="env://")
+    elif args.force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["DCFP_FORCE_SYNCBN"] = "1"
+        dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     H, W = [int(v) for v in args.size.split(",")]
 
     from dcfp_amd import optimizer as opt, pruners, ops
@@ -179,7 +186,10 @@ def main():
     optimizer.zero_grad()
     train_pruning = pruners.dcfp_pruning(seg_model, 0.999)
     engine = Engine(custom_parser=argparse.ArgumentParser())
-    model = engine.data_parallel(seg_model) if world > 1 else seg_model
+    if args.force_ddp and world == 1:
+        engine.distributed = True
+    ddp = world > 1 or args.force_ddp
+    model = engine.data_parallel(seg_model) if ddp else seg_model
     images, labels = synthetic_batch(args.batch, H, W, 12345 + rank, device)
     max_iter = 4000
 
@@ -187,7 +197,7 @@ def main():
         optimizer.zero_grad(set_to_none=False)
         opt.adjust_learning_rate(optimizer, 0.01, it, max_iter, 0.9, -1)
         loss = model(images, labels, deepsup=True)
-        reduce_loss = engine.all_reduce_tensor(loss["loss"]) if world > 1 else loss["loss"]
+        reduce_loss = engine.all_reduce_tensor(loss["loss"]) if ddp else loss["loss"]
         val = reduce_loss.item()              # the reference syncs here every iteration (train.py:263)
         if val != val:
             raise RuntimeError("loss is NaN")
@@ -245,7 +255,7 @@ def main():
                "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone) == (1024, 2048, "resnet101") else None,
                "roofline": roof, "cpu_baseline": cpu, "detail": extra}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

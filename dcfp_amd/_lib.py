@@ -51,7 +51,7 @@ SIGNATURES = {
     "dcfp_bn_stats_f32": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "dcfp_bn_apply_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P, _L, _I, _I, _I, _P]),
     "dcfp_bn_bwd_reduce_f32": (_I, [_P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
-    "dcfp_bn_bwd_apply_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _F, _P, _P, _F, _I, _P, _P,
+    "dcfp_bn_bwd_apply_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _F, _P, _P, _F, _P, _I, _P, _P,
                                    _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -65,6 +65,7 @@ SIGNATURES = {
     "dcfp_upsample_ce_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P,
                                       _Z, _P]),
     "dcfp_upsample_ce_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "dcfp_ohem_zoom_gt_prob_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dcfp_eic_update_f32": (_I, [_P, _I, _F, _F, _P]),
     "dcfp_sgd_momentum_f32": (_I, [_P, _I, _L, _F, _F, _I, _P]),
 }

@@ -206,8 +206,10 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
                     long long y_nstride, const float* __restrict__ mean,
                     const float* __restrict__ var, const float* __restrict__ gamma, float eps,
                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xmu,
-                    float inv_count, float* __restrict__ dx, float* __restrict__ dres, int C,
+                    float inv_count_host, const float* __restrict__ count_dev,
+                    float* __restrict__ dx, float* __restrict__ dres, int C,
                     int HW, int colchunks, int cols_per_block) {
+    const float inv_count = count_dev ? 1.0f / count_dev[0] : inv_count_host;
     const long long row = blockIdx.x / colchunks;
     const int chunk = blockIdx.x - (int)(row * colchunks);
     const int n = (int)(row / C), c = (int)(row - (long long)n * C);
@@ -341,10 +343,11 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
                                      const float* y, int64_t y_nstride, const float* mean,
                                      const float* var, const float* gamma, float eps,
                                      const float* sum_dy, const float* sum_dy_xmu, float count,
-                                     int relu, float* dx, float* d_residual, int N, int C,
-                                     int HW, dcfp_stream_t stream) {
+                                     const float* count_dev, int relu, float* dx,
+                                     float* d_residual, int N, int C, int HW,
+                                     dcfp_stream_t stream) {
     if (!dy || !x || !mean || !var || !gamma || !sum_dy || !sum_dy_xmu || !dx || N <= 0 ||
-        C <= 0 || HW <= 0 || !(count > 0.f))
+        C <= 0 || HW <= 0 || (!count_dev && !(count > 0.f)))
         return DCFP_E_BADDESC;
     if (relu && !y) return DCFP_E_BADDESC;
     if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
@@ -355,11 +358,12 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
     const bool vec = (HW % 4 == 0) && (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                      dcfp_aligned16(dy) && dcfp_aligned16(x) && dcfp_aligned16(dx) &&
                      (!relu || dcfp_aligned16(y)) && (!d_residual || dcfp_aligned16(d_residual));
-    const float inv_count = 1.0f / count;
+    const float inv_count = count > 0.f ? 1.0f / count : 0.f;
 #define LAUNCH_APP(V, R)                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R>), dim3((unsigned)blocks), dim3(kThreads), 0,    \
                        dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
-                       mean, var, gamma, eps, sum_dy, sum_dy_xmu, inv_count, dx, d_residual, C,   \
+                       mean, var, gamma, eps, sum_dy, sum_dy_xmu, inv_count, count_dev, dx,       \
+                       d_residual, C,                                                             \
                        HW, colchunks, kColsPerBlock)
     if (vec) { if (relu) LAUNCH_APP(true, true); else LAUNCH_APP(true, false); }
     else     { if (relu) LAUNCH_APP(false, true); else LAUNCH_APP(false, false); }

@@ -239,6 +239,56 @@ upsample_ce_bwd_kernel(const float* __restrict__ logits, const long long* __rest
     }
 }
 
+// OHEM threshold search input (loss/ohem.py:20-33): the reference zooms the full-resolution
+// softmax to 1/factor with scipy.ndimage.zoom(order=1) and the labels with order=0, then
+// gathers the zoomed probability of the zoomed label.  Per zoomed position that is a bilinear
+// blend of prob_L at four full-resolution pixels, L = nearest label — computed here from the
+// low-resolution logits and the per-pixel LSE without ever forming the probability tensor.
+// scipy's coordinate rule (grid_mode=False): src = o * (in-1)/(out-1), evaluated in double.
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+ohem_zoom_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                 const float* __restrict__ lse, int N, int C, int h, int w, int H, int W,
+                 float sh, float sw, int H8, int W8, float* __restrict__ pred8,
+                 int* __restrict__ lab8) {
+    const long long total = (long long)N * H8 * W8;
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int ox = (int)(idx % W8);
+        const long long t = idx / W8;
+        const int oy = (int)(t % H8);
+        const int n = (int)(t / H8);
+        const double cy = H8 > 1 ? (double)oy * (double)(H - 1) / (double)(H8 - 1) : 0.0;
+        const double cx = W8 > 1 ? (double)ox * (double)(W - 1) / (double)(W8 - 1) : 0.0;
+        int ny = (int)floor(cy + 0.5), nx = (int)floor(cx + 0.5);
+        ny = ny > H - 1 ? H - 1 : ny; nx = nx > W - 1 ? W - 1 : nx;
+        const long long L = labels[((long long)n * H + ny) * W + nx];
+        lab8[idx] = (int)L;
+        float out = 0.f;
+        if (L >= 0 && L < C) {
+            const int y0 = (int)floor(cy), x0 = (int)floor(cx);
+            const double ty = cy - y0, tx = cx - x0;
+            const float* p = logits + ((long long)n * C + L) * h * w;
+            double acc = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int Y = y0 + dy, X = x0 + dx;
+                    const double wgt = (dy ? ty : 1.0 - ty) * (dx ? tx : 1.0 - tx);
+                    if (Y > H - 1 || X > W - 1 || wgt == 0.0) continue;   // mode='constant', cval=0
+                    const Lerp Lh = lerp_of<ALIGN>(Y, sh, h), Lw = lerp_of<ALIGN>(X, sw, w);
+                    const float z = Lh.l0 * (Lw.l0 * p[Lh.i0 * w + Lw.i0] + Lw.l1 * p[Lh.i0 * w + Lw.i1]) +
+                                    Lh.l1 * (Lw.l0 * p[Lh.i1 * w + Lw.i0] + Lw.l1 * p[Lh.i1 * w + Lw.i1]);
+                    acc += wgt * (double)expf(z - lse[((long long)n * H + Y) * W + X]);
+                }
+            }
+            out = (float)acc;
+        }
+        pred8[idx] = out;
+    }
+}
+
 inline unsigned stream_grid(long long total) {
     long long b = (total + kThreads - 1) / kThreads;
     if (b > 256 * 16) b = 256 * 16;
@@ -332,5 +382,24 @@ extern "C" int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labe
         hipLaunchKernelGGL(upsample_ce_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
                            dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, C, h, w, H, W,
                            sh, sw, lse, grad_scale, dlogits);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_ohem_zoom_gt_prob_f32(const float* logits, const int64_t* labels, const float* lse,
+                                          int N, int C, int h, int w, int H, int W,
+                                          int align_corners, int H8, int W8, float* pred8,
+                                          int32_t* lab8, dcfp_stream_t stream) {
+    if (!logits || !labels || !lse || !pred8 || !lab8 || N <= 0 || C <= 0 || h <= 0 || w <= 0 ||
+        H <= 0 || W <= 0 || H8 <= 0 || W8 <= 0)
+        return DCFP_E_BADDESC;
+    const long long total = (long long)N * H8 * W8;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    const long long* lab = reinterpret_cast<const long long*>(labels);
+    if (align_corners)
+        hipLaunchKernelGGL(ohem_zoom_kernel<true>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, lse, N, C, h, w, H, W, sh, sw, H8, W8, pred8, lab8);
+    else
+        hipLaunchKernelGGL(ohem_zoom_kernel<false>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, lse, N, C, h, w, H, W, sh, sw, H8, W8, pred8, lab8);
     DCFP_RETURN_LAUNCH();
 }

@@ -1,24 +1,21 @@
 """OHEM cross-entropy — API of loss/ohem.py:9-119.
 
-Reference flow: softmax on device -> full-resolution probabilities copied to the host ->
-scipy zoom to 1/8 -> k-th smallest ground-truth probability via np.partition -> threshold
-max(thresh, kth) -> pixels with gt-prob > threshold relabelled ignore -> CE.
-Here the per-pixel ground-truth probability comes out of the fused upsample+CE forward
-kernel (gt_prob), only the 1/factor-subsampled probabilities (N*H*W/64 floats) are used for
-the k-th-smallest selection, and the kept-pixel mask feeds the same fused CE kernels, so the
-full-resolution probability tensor never exists and nothing but one scalar is reduced."""
+Reference flow: softmax on device -> FULL-resolution probabilities copied to the host ->
+scipy zoom to 1/8 (order 1 for probabilities, order 0 for labels) -> k-th smallest
+ground-truth probability via np.partition -> threshold = max(thresh, kth) -> pixels whose
+ground-truth probability exceeds the threshold are relabelled ignore -> CE.
+Here nothing full-resolution but one float per pixel exists: the fused upsample+CE forward
+kernel yields the per-pixel LSE and label-class probability, `dcfp_ohem_zoom_gt_prob_f32`
+evaluates the zoomed ground-truth probability on the 1/8 grid with scipy's coordinate rule,
+the k-th smallest of those ~N*H*W/64 values is selected on the device, and the kept-pixel mask
+feeds the same fused CE kernels."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
-from .. import ops
-
-
-def zoom_nearest_index(out_len, in_len):
-    """Source index scipy.ndimage.zoom(order=0/1, mode='constant', grid_mode=False) samples
-    for each output index: coordinate o * (in-1)/(out-1)  (ohem.py:22-23)."""
-    if out_len <= 1:
-        return torch.zeros(max(out_len, 1), dtype=torch.float64)
-    return torch.arange(out_len, dtype=torch.float64) * ((in_len - 1) / (out_len - 1))
+from .. import _lib, ops
+from .._lib import check
 
 
 class OhemCrossEntropy2d(nn.Module):
@@ -32,46 +29,40 @@ class OhemCrossEntropy2d(nn.Module):
         self.factor = factor
 
     @torch.no_grad()
-    def find_threshold(self, gt_prob, target):
-        """Device restatement of ohem.py:20-48 on the label-class probability map
-        gt_prob[N,H,W] (the reference gathers the same quantity from the zoomed softmax)."""
-        N, H, W = target.shape
+    def find_threshold(self, logits, target, lse, size, align_corner):
+        """ohem.py:20-48 on the device; returns a python float like the reference."""
+        logits = logits.contiguous()
+        N, Cc, h, w = logits.shape
+        H, W = int(size[0]), int(size[1])
         f = self.factor
-        h, w = int(round(H / f)), int(round(W / f))
-        dev = gt_prob.device
-        ys = zoom_nearest_index(h, H).to(dev)
-        xs = zoom_nearest_index(w, W).to(dev)
-        # labels: order-0 (nearest, round-half-even like scipy's spline order 0 == floor(x+0.5))
-        yi = torch.floor(ys + 0.5).long().clamp_(0, H - 1)
-        xi = torch.floor(xs + 0.5).long().clamp_(0, W - 1)
-        lab = target[:, yi][:, :, xi]
-        # probabilities: order-1 (bilinear) zoom of the probability map
-        y0 = torch.floor(ys).long().clamp_(0, H - 1); y1 = (y0 + 1).clamp_(max=H - 1)
-        x0 = torch.floor(xs).long().clamp_(0, W - 1); x1 = (x0 + 1).clamp_(max=W - 1)
-        ly = (ys - y0.double()).float().view(1, -1, 1); lx = (xs - x0.double()).float().view(1, 1, -1)
-        g = gt_prob
-        top = g[:, y0][:, :, x0] * (1 - lx) + g[:, y0][:, :, x1] * lx
-        bot = g[:, y1][:, :, x0] * (1 - lx) + g[:, y1][:, :, x1] * lx
-        prob = top * (1 - ly) + bot * ly
+        H8, W8 = int(round(H * (1.0 / f))), int(round(W * (1.0 / f)))   # scipy: round(in * zoom)
+        pred8 = torch.empty((N, H8, W8), dtype=torch.float32, device=logits.device)
+        lab8 = torch.empty((N, H8, W8), dtype=torch.int32, device=logits.device)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(_lib.lib().dcfp_ohem_zoom_gt_prob_f32(
+            C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()), C.c_void_p(lse.data_ptr()),
+            N, Cc, h, w, H, W, int(bool(align_corner)), H8, W8, C.c_void_p(pred8.data_ptr()),
+            C.c_void_p(lab8.data_ptr()), stream), "ohem_zoom")
         min_kept = self.min_kept // (f * f)
-        valid = lab != self.ignore_label
+        valid = lab8 != self.ignore_label
         num_valid = int(valid.sum().item())
         if min_kept >= num_valid:
             return 1.0
         threshold = self.thresh
         if num_valid > 0 and min_kept > 0:
-            pred = prob[valid]
+            pred = pred8[valid]
             k_th = min(pred.numel(), min_kept) - 1
-            kth_val = torch.kthvalue(pred, k_th + 1).values.item()
+            kth_val = float(torch.kthvalue(pred, k_th + 1).values.item())
             if kth_val > self.thresh:
                 threshold = kth_val
         return threshold
 
     def forward_lowres(self, logits, target, size, align_corner):
+        target = target.contiguous()
         out2, lse, gtp = ops.upsample_ce_forward(logits.detach(), target, size, align_corner,
                                                  self.ignore_label, want_gt_prob=True)
-        threshold = self.find_threshold(gtp, target)
-        keep = (gtp <= threshold)  # ohem.py:69: kept_flag = pred <= threshold
+        threshold = self.find_threshold(logits.detach(), target, lse, size, align_corner)
+        keep = gtp <= threshold   # ohem.py:69: kept_flag = pred <= threshold
         return ops.upsample_cross_entropy(logits, target, size, align_corner, self.ignore_label,
                                           pixel_keep=keep)
 

@@ -5,6 +5,7 @@ moved on the hot path below happens in libdcfp_hip.so.  Inputs must be CUDA (HIP
 tensors — there is deliberately no CPU / eager fallback.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -225,10 +226,13 @@ def bn_bwd_apply(dy, x, y, mean, var, gamma, eps, s1, s2, count, relu, want_resi
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual else None
     nbytes = (12.0 + (4.0 if relu else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
+    count_dev = count if isinstance(count, torch.Tensor) else None   # SyncBN: global count on device
+    count_host = 0.0 if count_dev is not None else float(count)
     _timed("bn_bwd_apply", None, nbytes, lambda: check(
         _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean),
-                                         _p(var), _p(gamma), float(eps), _p(s1), _p(s2), float(count),
-                                         int(relu), _p(dx), _p(dres), N, Cc, H * W, _stream()),
+                                         _p(var), _p(gamma), float(eps), _p(s1), _p(s2), count_host,
+                                         _p(count_dev), int(relu), _p(dx), _p(dres), N, Cc, H * W,
+                                         _stream()),
         "bn_bwd_apply"))
     return dx, dres
 
@@ -237,8 +241,8 @@ def _sync_group(group):
     if group is False or not dist.is_available() or not dist.is_initialized():
         return None
     g = None if group is True else group
-    if dist.get_world_size(g) <= 1:
-        return None
+    if dist.get_world_size(g) <= 1 and not os.environ.get("DCFP_FORCE_SYNCBN"):
+        return None   # (the env switch rehearses the exchange at world size 1)
     return g if g is not None else dist.group.WORLD
 
 
@@ -255,7 +259,7 @@ def sync_bn_stats(mean, var, count, group):
     total = counts.sum()
     gmean = (means * counts).sum(0) / total
     gvar = ((vars_ + (means - gmean) ** 2) * counts).sum(0) / total
-    return gmean.contiguous(), gvar.contiguous(), float(total.item())
+    return gmean.contiguous(), gvar.contiguous(), total.reshape(1).contiguous()  # no host sync
 
 
 def sync_bn_bwd_sums(s1, s2, group):
@@ -287,7 +291,10 @@ class BatchNormActFn(torch.autograd.Function):
                 mean, var, count = sync_bn_stats(mean, var, count, group)
             if running_mean is not None and momentum is not None:
                 with torch.no_grad():
-                    unbiased = var * (count / max(count - 1.0, 1.0))
+                    if isinstance(count, torch.Tensor):
+                        unbiased = var * (count / (count - 1.0).clamp_(min=1.0))
+                    else:
+                        unbiased = var * (count / max(count - 1.0, 1.0))
                     running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
                     running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
         else:

@@ -109,11 +109,13 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                            float* sum_dy, float* sum_dy_xmu,
                            void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
 /* Backward stage 2: dx = gamma*istd*( g - sum_dy/M - (x-mean)*istd^2*sum_dy_xmu/M ),
- * M = count (N*HW, or the global count under SyncBN); d_residual (nullable) = g. */
+ * M = count (N*HW); under SyncBN the global count lives on the device: count_dev (nullable,
+ * one float) then overrides `count` without a host round trip.  d_residual (nullable) = g. */
 int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
                           const float* y, int64_t y_nstride, const float* mean,
                           const float* var, const float* gamma, float eps,
                           const float* sum_dy, const float* sum_dy_xmu, float count,
+                          const float* count_dev,
                           int relu, float* dx, float* d_residual,
                           int N, int C, int HW, dcfp_stream_t stream);
 
@@ -170,6 +172,15 @@ int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labels,
                              int N, int C, int h, int w, int H, int W, int align_corners,
                              const float* lse, const float* grad_scale /* device scalar */,
                              float* dlogits, dcfp_stream_t stream);
+
+/* OHEM threshold input (loss/ohem.py:20-33): per position of the 1/factor-zoomed grid
+ * (H8 x W8 = round(H/factor) x round(W/factor), scipy.ndimage.zoom coordinates) the nearest
+ * label (lab8) and the order-1-zoomed softmax probability of that label (pred8), computed from
+ * the low-resolution logits and the LSE map of dcfp_upsample_ce_fwd_f32. */
+int dcfp_ohem_zoom_gt_prob_f32(const float* logits, const int64_t* labels, const float* lse,
+                               int N, int C, int h, int w, int H, int W, int align_corners,
+                               int H8, int W8, float* pred8, int32_t* lab8,
+                               dcfp_stream_t stream);
 
 /* ------------------------------------------------------------- EIC score
  * dcfp_pruning.step (pruners/dcfp_pruner.py:15-20), all scored BN layers in one

@@ -32,7 +32,7 @@ def _worker(rank, world, port, ret):
     shard = full[:2] if rank == 0 else full[2:]
     mean = shard.mean((0, 2, 3)); var = shard.var((0, 2, 3), unbiased=False)
     gm, gv, cnt = ops.sync_bn_stats(mean, var, shard.numel() // 7, dist.group.WORLD)
-    assert cnt == full.numel() // 7
+    assert float(cnt) == full.numel() // 7
     assert torch.allclose(gm, full.mean((0, 2, 3)), atol=1e-6)
     assert torch.allclose(gv, full.var((0, 2, 3), unbiased=False), atol=1e-5)
     # backward sums

@@ -192,3 +192,36 @@ def test_upsample_ce_all_ignored(cuda):
     lab = torch.full((1, 9, 9), 255, dtype=torch.int64)
     out = ops.upsample_cross_entropy(z.to(cuda), lab.to(cuda), (9, 9), True, 255)
     assert math.isnan(out.item())      # torch: mean over zero valid pixels = nan
+
+
+@pytest.mark.parametrize("case", ["kth_le", "kth_gt", "few_valid"])
+def test_ohem_threshold_and_loss_vs_oracle(cuda, case):
+    """OHEM on the device (zoomed ground-truth probability, k-th smallest, kept mask, CE) against
+    the numpy/scipy restatement of loss/ohem.py, on the reference-pinned golden cases."""
+    import os
+    import numpy as np
+    from oracle import ohem as oohem
+    from dcfp_amd.loss.ohem import OhemCrossEntropy2d
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ohem_threshold.npz"))
+    z = torch.from_numpy(g[f"z:{case}"]); lab = torch.from_numpy(g[f"lab:{case}"]).long()
+    mk = int(g[f"min_kept:{case}"])
+    prob = torch.softmax(z, 1).numpy()
+    new_t, th = oohem.new_target(prob, lab.numpy(), 255, 0.7, mk)
+    assert float(th) == float(g[f"th:{case}"])          # oracle == reference (golden)
+    zr = z.double().requires_grad_(True)
+    ref_loss = F.cross_entropy(zr, torch.from_numpy(new_t).long(), ignore_index=255)
+    ref_loss.backward()
+    crit = OhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=mk)
+    zg = z.to(cuda).requires_grad_(True)
+    H, W = lab.shape[-2:]
+    out2, lse, gtp = __import__("dcfp_amd").ops.upsample_ce_forward(zg.detach(), lab.to(cuda), (H, W), True, 255,
+                                                                    want_gt_prob=True)
+    th_gpu = crit.find_threshold(zg.detach(), lab.to(cuda), lse, (H, W), True)
+    assert abs(th_gpu - float(th)) <= 2e-6 * max(1.0, abs(float(th))), (th_gpu, th)
+    loss = crit.forward_lowres(zg, lab.to(cuda), (H, W), True)
+    loss.backward()
+    if math.isnan(ref_loss.item()):
+        assert math.isnan(loss.item())
+    else:
+        assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+        assert rel_err(zg.grad, zr.grad) < 1e-3
