@@ -547,6 +547,19 @@ bias_grad_kernel(const float* __restrict__ dy, long long dy_nstride, float* __re
     if (threadIdx.x == 0) db[c] = t;
 }
 
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;   // MI355X; also the answer when no device is present (CPU-side queries)
+    }
+    return n;
+}
+
 struct Plan {
     int bm, bn, cfg;  // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave)
     int tiles_m, tiles_n, splits, kchunk;
@@ -562,10 +575,26 @@ Plan make_plan(const DcfpConvDesc* d) {
     pl.tiles_n = (Nn + pl.bn - 1) / pl.bn;
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
     const long long Kpix = (long long)d->N * d->Hout * d->Wout;
-    // ~2 blocks per CU for the big tiles, ~8 for the one-wave tile; >= 8 K-steps per split
-    const long long target = pl.cfg == 2 ? 2048 : 512;
-    long long splits = (target + tiles - 1) / tiles;
-    const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);
+    // Split K so that the grid fills whole "rounds" of the chip: the big tiles run one
+    // workgroup per CU (512 registers/lane), so tiles*splits just above a multiple of the CU
+    // count wastes most of a round (513 blocks on 256 CUs took 1.35x the time of 252).
+    const int cus = num_cus();
+    const long long per_cu = pl.cfg == 2 ? 8 : 1;            // resident workgroups per CU
+    const long long slots = (long long)cus * per_cu;
+    const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);   // >= 8 K-steps per split
+    long long splits = 1;
+    if (const char* e = getenv("DCFP_DBG_WGRAD_BLOCKS")) {
+        splits = (atoll(e) + tiles - 1) / tiles;
+    } else {
+        double best = -1.0;
+        for (long long sp = 1; sp <= max_splits && tiles * sp <= 4 * slots; ++sp) {
+            const long long blocks = tiles * sp;
+            const long long rounds = (blocks + slots - 1) / slots;
+            double eff = (double)blocks / (double)(rounds * slots);
+            if (blocks < slots) eff *= 0.999;                // prefer filling the chip at equal eff
+            if (eff > best + 0.02) { best = eff; splits = sp; }   // smallest split within 2 % of best
+        }
+    }
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long long kchunk = (Kpix + splits - 1) / splits;
