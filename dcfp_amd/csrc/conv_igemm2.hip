@@ -84,7 +84,8 @@ struct Frag<1> {
     static __device__ __forceinline__ void ld(const float* p, float (&f)[1]) { f[0] = p[0]; }
 };
 
-template <int TAPS, int TM, int TN, int WM, int WN, bool SD>
+// ACC: dx += result (gradient fan-in of a residual branch); only the epilogue differs.
+template <int TAPS, int TM, int TN, int WM, int WN, bool SD, bool ACC>
 __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     // A: thread -> (4 consecutive m, rows ay + AROWS*j)
@@ -271,14 +272,36 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
     float* o_img = p.out + (long long)img * p.out_nstride;
     int pix = p0 + wn * (TN * 32) + TN * l31;
     asm volatile("" : "+v"(pix));
+    const bool vec = (TN == 4) && p.vec_store && (pix + 3 < p.P);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        float4 old[16];
+        if (ACC) {   // 16 independent loads in flight per batch, not a serialized read-modify-write
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int m = m0 + wm * (TM * 32) + TM * row + i;
+                const float* src = o_img + (long long)m * p.P + pix;
+                old[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.M) {
+                    if (vec) {
+                        old[r] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (pix + 0 < p.P) old[r].x = src[0];
+                        if (TN > 1 && pix + 1 < p.P) old[r].y = src[1];
+                        if (TN > 2 && pix + 2 < p.P) old[r].z = src[2];
+                        if (TN > 3 && pix + 3 < p.P) old[r].w = src[3];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
             const int m = m0 + wm * (TM * 32) + TM * row + i;
             if (m >= p.M) continue;
-            float v[TN];
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
             if (p.bias) {
@@ -286,32 +309,29 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
 #pragma unroll
                 for (int j = 0; j < TN; ++j) v[j] += bsv;
             }
+            if (ACC) { v[0] += old[r].x; v[1] += old[r].y; v[2] += old[r].z; v[3] += old[r].w; }
             float* dst = o_img + (long long)m * p.P + pix;
-            if (TN == 4 && p.vec_store && pix + 3 < p.P) {
-                float4 o = make_float4(v[0], v[1], v[TN > 2 ? 2 : 0], v[TN > 3 ? 3 : 0]);
-                if (p.accumulate) {
-                    const float4 old = *reinterpret_cast<const float4*>(dst);
-                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-                }
-                *reinterpret_cast<float4*>(dst) = o;
+            if (vec) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (pix + j < p.P) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+                    if (pix + j < p.P) dst[j] = v[j];
                 }
             }
         }
+        if (ACC) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int TAPS, int TM, int TN, int WM, int WN, bool SD = false>
+template <int TAPS, int TM, int TN, int WM, int WN, bool SD = false, bool ACC = false>
 int launch_cfg(Igemm2Params& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     const long long groups = ((long long)p.tiles_n_total + 7) / 8;
     const long long blocks = groups * 8 * p.tiles_m;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
-    auto kern = igemm2_kernel<TAPS, TM, TN, WM, WN, SD>;
+    auto kern = igemm2_kernel<TAPS, TM, TN, WM, WN, SD, ACC>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -336,6 +356,14 @@ TileCfg pick_cfg(int M, long long px, int sd) {
 
 template <int TAPS>
 int launch_taps(Igemm2Params& p, int cfg, hipStream_t stream) {
+    if (p.accumulate) {   // residual-gradient fan-in: block inputs have >= 128 channels
+        switch (cfg) {
+            case 2: return launch_cfg<TAPS, 2, 4, 2, 2, false, true>(p, stream);
+            case 3: return launch_cfg<TAPS, 2, 2, 2, 2, false, true>(p, stream);
+            case 4: return launch_cfg<TAPS, 4, 4, 2, 2, false, true>(p, stream);
+            default: return DCFP_E_UNSUPPORTED;
+        }
+    }
     switch (cfg) {
         case 0: return launch_cfg<TAPS, 1, 4, 1, 4>(p, stream);
         case 1: return launch_cfg<TAPS, 2, 4, 1, 4>(p, stream);

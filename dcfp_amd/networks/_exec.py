@@ -18,8 +18,14 @@ def conv(m, x):
     return ops.conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], m.dilation[0])
 
 
-def bn_act(m, x, relu=False, residual=None):
-    """BatchNorm2d / SyncBatchNorm (+ReLU) (+residual add before the ReLU)."""
+import os
+
+FUSE_BLOCKS = os.environ.get("DCFP_NO_BLOCK_FUSION") is None
+
+
+def _bn_args(m):
+    """(running_mean, running_var, training, momentum, eps, sync) of a BN module, with the
+    module-side bookkeeping nn.BatchNorm2d.forward does (num_batches_tracked)."""
     training = m.training or (m.running_mean is None)
     sync = False
     if isinstance(m, nn.SyncBatchNorm) and training:
@@ -31,8 +37,40 @@ def bn_act(m, x, relu=False, residual=None):
             momentum = 1.0 / float(m.num_batches_tracked)
     if not m.affine:
         raise RuntimeError("dcfp_amd: BatchNorm without affine parameters is not on the DCFP path")
-    return ops.batch_norm_act(x, m.weight, m.bias, m.running_mean, m.running_var, residual, relu,
-                              training, momentum, m.eps, sync)
+    return (m.running_mean, m.running_var, training, momentum, m.eps, sync)
+
+
+def bn_act(m, x, relu=False, residual=None):
+    """BatchNorm2d / SyncBatchNorm (+ReLU) (+residual add before the ReLU)."""
+    rm, rv, training, momentum, eps, sync = _bn_args(m)
+    return ops.batch_norm_act(x, m.weight, m.bias, rm, rv, residual, relu, training, momentum, eps, sync)
+
+
+def _plain_conv(m, k):
+    ok = (m.groups == 1 and m.bias is None and m.kernel_size == (k, k) and m.padding_mode == "zeros"
+          and not isinstance(m.padding, str))
+    if not ok:
+        raise RuntimeError(f"dcfp_amd: unsupported conv configuration in Bottleneck: {m}")
+
+
+def bottleneck(blk, x):
+    """Run a reference Bottleneck (resnet.py:38-58) as the fused ops.BottleneckFn node."""
+    _plain_conv(blk.conv1, 1); _plain_conv(blk.conv2, 3); _plain_conv(blk.conv3, 1)
+    bns = [blk.bn1, blk.bn2, blk.bn3]
+    tensors = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight,
+               blk.bn2.bias, blk.conv3.weight, blk.bn3.weight, blk.bn3.bias]
+    stride, dil = blk.conv2.stride[0], blk.conv2.dilation[0]
+    if blk.conv2.padding[0] != dil or blk.conv1.stride[0] != 1 or blk.conv3.stride[0] != 1:
+        raise RuntimeError("dcfp_amd: unexpected Bottleneck geometry")
+    if blk.downsample is not None:
+        dconv, dbn = blk.downsample[0], blk.downsample[1]
+        _plain_conv(dconv, 1)
+        if dconv.stride[0] != stride:
+            raise RuntimeError("dcfp_amd: downsample stride differs from conv2 stride")
+        tensors += [dconv.weight, dbn.weight, dbn.bias]
+        bns.append(dbn)
+    cfg = {"stride": stride, "dil": dil, "bn": [_bn_args(b) for b in bns]}
+    return ops.bottleneck(x, cfg, tensors)
 
 
 def run_sequential(seq, x):

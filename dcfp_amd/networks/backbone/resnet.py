@@ -35,6 +35,8 @@ class Bottleneck(nn.Module):
         self.dilation = dilation
 
     def forward(self, x):
+        if _exec.FUSE_BLOCKS and x.requires_grad:
+            return _exec.bottleneck(self, x)   # one autograd node; residual grad fused into dgrad
         out = _exec.bn_act(self.bn1, _exec.conv(self.conv1, x), relu=True)
         out = _exec.bn_act(self.bn2, _exec.conv(self.conv2, out), relu=True)
         out = _exec.conv(self.conv3, out)

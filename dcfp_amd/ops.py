@@ -120,17 +120,24 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1):
     return y
 
 
-def conv2d_dgrad(dy, w, xshape, stride, pad, dil):
+def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
+    """dx = conv_transpose(dy, w); with accumulate, `out` (+)= the result in place."""
     _require(dy, "dy")
     w = w.contiguous()
     d = _desc(xshape, w.shape, stride, pad, dil)
     dy, ns = _batch_strided(dy)
-    dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+    if out is not None:
+        if tuple(out.shape) != tuple(xshape) or not out.is_contiguous():
+            raise RuntimeError("conv2d_dgrad: out must be a contiguous tensor of the input shape")
+        dx = out
+    else:
+        dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+        accumulate = False
     L = _lib.lib()
     ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_DGRAD), dy.device)
     _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
-        L.dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), 0, _p(ws), ws.numel(),
-                                     _stream()), "conv2d_dgrad"))
+        L.dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), int(bool(accumulate)),
+                                     _p(ws), ws.numel(), _stream()), "conv2d_dgrad"))
     return dx
 
 
@@ -270,6 +277,48 @@ def sync_bn_bwd_sums(s1, s2, group):
     return both[:Cc].contiguous(), both[Cc:].contiguous()
 
 
+def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, training,
+                    momentum, eps, sync):
+    """Shared BN(+ReLU)(+residual) forward: returns (y, state) with state =
+    (mean, var, count, group) for the backward."""
+    _require(x, "x")
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    count = float(N * H * W)
+    group = _sync_group(sync) if training else None
+    if training:
+        mean, var = bn_stats(x)
+        if group is not None:
+            mean, var, count = sync_bn_stats(mean, var, count, group)
+        if running_mean is not None and momentum is not None:
+            with torch.no_grad():
+                if isinstance(count, torch.Tensor):
+                    unbiased = var * (count / (count - 1.0).clamp_(min=1.0))
+                else:
+                    unbiased = var * (count / max(count - 1.0, 1.0))
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
+    else:
+        mean, var = running_mean, running_var
+    y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
+    return y, (mean, var, count, group)
+
+
+def bn_backward_impl(dy, x, y, gamma, state, relu, training, eps, want_res):
+    """Shared backward: returns (dx, dgamma, dbeta, dres).  dgamma/dbeta are this rank's sums
+    (the gradient all-reduce averages them); under SyncBN the sums entering dx are global."""
+    mean, var, count, group = state
+    s1, s2 = bn_bwd_reduce(dy, x, y, mean, relu)
+    dgamma = s2 * torch.rsqrt(var + eps)
+    dbeta = s1
+    if training:
+        r1, r2 = sync_bn_bwd_sums(s1, s2, group) if group is not None else (s1, s2)
+    else:  # running statistics are constants: dx = g * gamma * istd
+        r1 = torch.zeros_like(s1); r2 = torch.zeros_like(s2)
+    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, eps, r1, r2, count, relu, want_res)
+    return dx, dgamma, dbeta, dres
+
+
 class BatchNormActFn(torch.autograd.Function):
     """y = act(BN(x) [+ residual]) with batch statistics (training) or running statistics
     (eval).  Mirrors nn.BatchNorm2d + nn.ReLU(inplace) (+ the Bottleneck residual add,
@@ -280,48 +329,94 @@ class BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, training,
                 momentum, eps, sync):
-        _require(x, "x")
         x = x.contiguous()
-        N, Cc, H, W = x.shape
-        count = float(N * H * W)
-        group = _sync_group(sync) if training else None
-        if training:
-            mean, var = bn_stats(x)
-            if group is not None:
-                mean, var, count = sync_bn_stats(mean, var, count, group)
-            if running_mean is not None and momentum is not None:
-                with torch.no_grad():
-                    if isinstance(count, torch.Tensor):
-                        unbiased = var * (count / (count - 1.0).clamp_(min=1.0))
-                    else:
-                        unbiased = var * (count / max(count - 1.0, 1.0))
-                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
-        else:
-            mean, var = running_mean, running_var
-        y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
-        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
-        ctx.cfg = (relu, training, eps, count, group, residual is not None)
+        y, state = bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu,
+                                   training, momentum, eps, sync)
+        mean, var, count, group = state
+        ctx.save_for_backward(x, y if relu else None, mean, var, gamma,
+                              count if isinstance(count, torch.Tensor) else None)
+        ctx.cfg = (relu, training, eps, None if isinstance(count, torch.Tensor) else count, group,
+                   residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, gamma = ctx.saved_tensors
+        x, y, mean, var, gamma, count_t = ctx.saved_tensors
         relu, training, eps, count, group, has_res = ctx.cfg
-        s1, s2 = bn_bwd_reduce(dy, x, y, mean, relu)
-        istd = torch.rsqrt(var + eps)
-        dgamma = s2 * istd
-        dbeta = s1
-        if training:
-            if group is not None:
-                r1, r2 = sync_bn_bwd_sums(s1, s2, group)
-            else:
-                r1, r2 = s1, s2
-        else:  # running statistics are constants: dx = g * gamma * istd
-            r1 = torch.zeros_like(s1); r2 = torch.zeros_like(s2)
+        state = (mean, var, count_t if count_t is not None else count, group)
         need_res = has_res and ctx.needs_input_grad[5]
-        dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, eps, r1, r2, count, relu, need_res)
+        dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, state, relu, training, eps, need_res)
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+class BottleneckFn(torch.autograd.Function):
+    """One residual Bottleneck (networks/backbone/resnet.py:38-58) as a single autograd node:
+    1x1 -> BN,ReLU -> 3x3(dil) -> BN,ReLU -> 1x1 -> BN (+residual) -> ReLU, with an optional
+    1x1(stride)+BN downsample on the residual.  Same kernels as the op-level Functions; what the
+    fusion buys is the backward: the block input receives two gradients (through conv1 and
+    through the residual), and here conv1's dgrad ACCUMULATES into the residual gradient buffer
+    instead of autograd materialising both and adding them (33 full-size adds per step)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *tensors):
+        # tensors: w1,g1,b1, w2,g2,b2, w3,g3,b3 [, wd,gd,bd]; cfg: dict of python values + BN buffers
+        x = x.contiguous()
+        has_ds = len(tensors) == 12
+        w1, g1, b1, w2, g2, b2, w3, g3, b3 = tensors[:9]
+        bnargs = cfg["bn"]   # per BN: (running_mean, running_var, training, momentum, eps, sync)
+        stride, dil = cfg["stride"], cfg["dil"]
+        c1 = conv2d_fwd(x, w1)
+        y1, st1 = bn_forward_impl(c1, g1, b1, bnargs[0][0], bnargs[0][1], None, True, *bnargs[0][2:])
+        c2 = conv2d_fwd(y1, w2, None, stride, dil, dil)
+        y2, st2 = bn_forward_impl(c2, g2, b2, bnargs[1][0], bnargs[1][1], None, True, *bnargs[1][2:])
+        c3 = conv2d_fwd(y2, w3)
+        if has_ds:
+            wd, gd, bd = tensors[9:]
+            cd = conv2d_fwd(x, wd, None, stride, 0, 1)
+            res, std = bn_forward_impl(cd, gd, bd, bnargs[3][0], bnargs[3][1], None, False, *bnargs[3][2:])
+        else:
+            cd, res, std = None, x, None
+        out, st3 = bn_forward_impl(c3, g3, b3, bnargs[2][0], bnargs[2][1], res, True, *bnargs[2][2:])
+        ctx.has_ds = has_ds
+        ctx.cfg = (stride, dil, [a[2] for a in bnargs], [a[4] for a in bnargs])
+        ctx.states = (st1, st2, st3, std)
+        ctx.save_for_backward(x, c1, y1, c2, y2, c3, out, cd, *tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c1, y1, c2, y2, c3, out, cd = ctx.saved_tensors[:8]
+        tensors = ctx.saved_tensors[8:]
+        w1, g1, b1, w2, g2, b2, w3, g3, b3 = tensors[:9]
+        stride, dil, training, eps = ctx.cfg
+        st1, st2, st3, std = ctx.states
+        # bn3 (+residual, ReLU): gradient of conv3's output and of the residual branch
+        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, st3, True, training[2], eps[2], True)
+        d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
+        dw3, _ = conv2d_wgrad(d_c3, y2, tuple(w3.shape), 1, 0, 1)
+        d_c2, dg2, db2, _ = bn_backward_impl(d_y2, c2, y2, g2, st2, True, training[1], eps[1], False)
+        d_y1 = conv2d_dgrad(d_c2, w2, tuple(y1.shape), stride, dil, dil)
+        dw2, _ = conv2d_wgrad(d_c2, y1, tuple(w2.shape), stride, dil, dil)
+        d_c1, dg1, db1, _ = bn_backward_impl(d_y1, c1, y1, g1, st1, True, training[0], eps[0], False)
+        dw1, _ = conv2d_wgrad(d_c1, x, tuple(w1.shape), 1, 0, 1)
+        grads = [dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3]
+        if ctx.has_ds:
+            wd, gd, bd = tensors[9:]
+            d_cd, dgd, dbd, _ = bn_backward_impl(d_res, cd, None, gd, std, False, training[3], eps[3], False)
+            dwd, _ = conv2d_wgrad(d_cd, x, tuple(wd.shape), stride, 0, 1)
+            grads += [dwd, dgd, dbd]
+            dx = conv2d_dgrad(d_cd, wd, tuple(x.shape), stride, 0, 1) if ctx.needs_input_grad[0] else None
+        else:
+            dx = d_res
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(d_c1, w1, tuple(x.shape), 1, 0, 1, out=dx, accumulate=True)
+        else:
+            dx = None
+        return (dx, None) + tuple(grads)
+
+
+def bottleneck(x, cfg, tensors):
+    return BottleneckFn.apply(x, cfg, *tensors)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
