@@ -130,8 +130,20 @@ def roofline_from_profile(recs, images_per_step, step_s):
     convs = {k: v for k, v in agg.items() if "kernel<" in k}
     dom = max(convs, key=lambda k: convs[k][1])
     w, ms, cnt = convs[dom]
+    # HBM-side bytes per launch from the committed PMC profile (cannot be collected inside this
+    # process): corrected FETCH_SIZE + WRITE_SIZE of the same kernel instance on its dominant shape
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")) as f:
+            tk = json.load(f)["kernels"].get(dom)
+        if tk:
+            traffic = tk["fetch_bytes_corrected"] + tk["write_bytes"]
+    except Exception:
+        pass
     roof = {"bound": "mfma", "kernel": dom, "achieved": w / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / PEAK_F32_MFMA, "traffic": None,
+            "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / PEAK_F32_MFMA, "traffic": traffic,
+            "traffic_note": "bytes/launch beyond L2 (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, "
+                            "profiles/r01_conv_traffic_pmc.txt; layer3 conv2 shape)" if traffic else None,
             "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "flop_per_launch": w / cnt,
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
     others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1], "launches": v[2]}
