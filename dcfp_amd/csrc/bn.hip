@@ -11,6 +11,12 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// The BN output value, written ONE way so that the forward kernel and the backward kernels
+// that re-derive the ReLU mask from x round identically.
+__device__ __forceinline__ float bn_val(float v, float mu, float istd, float g, float b) {
+    return fmaf((v - mu) * istd, g, b);
+}
+
 struct BnPlan {
     int chunks;       // blocks per channel
     int chunk_elems;  // elements (of the N*HW per-channel population) per block, multiple of 4
@@ -113,10 +119,10 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
         for (int i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kThreads) {
             const float4 v = *reinterpret_cast<const float4*>(xr + i);
             float4 o;
-            o.x = (v.x - mu) * istd * g + b;
-            o.y = (v.y - mu) * istd * g + b;
-            o.z = (v.z - mu) * istd * g + b;
-            o.w = (v.w - mu) * istd * g + b;
+            o.x = bn_val(v.x, mu, istd, g, b);
+            o.y = bn_val(v.y, mu, istd, g, b);
+            o.z = bn_val(v.z, mu, istd, g, b);
+            o.w = bn_val(v.w, mu, istd, g, b);
             if (rr) {
                 const float4 r = *reinterpret_cast<const float4*>(rr + i);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -129,7 +135,7 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
         }
     } else {
         for (int i = i0 + threadIdx.x; i < i1; i += kThreads) {
-            float o = (xr[i] - mu) * istd * g + b;
+            float o = bn_val(xr[i], mu, istd, g, b);
             if (rr) o += rr[i];
             if (relu) o = o > 0.f ? o : 0.f;
             yr[i] = o;
@@ -138,15 +144,21 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
 }
 
 // ---- backward stage 1: S1 = sum g, S2 = sum g*(x-mean),  g = dy*(y>0)
-template <bool VEC, bool RELU>
+// RELU: 0 none, 1 mask from the saved output y, 2 mask re-derived from x (no residual: y is a
+// function of x alone, so the 4 B/element read of y is skipped)
+template <bool VEC, int RELU>
 __global__ void __launch_bounds__(kThreads)
 bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
                              const float* __restrict__ x, const float* __restrict__ y,
-                             long long y_nstride, const float* __restrict__ mean, int C, int HW,
+                             long long y_nstride, const float* __restrict__ mean,
+                             const float* __restrict__ var, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, float eps, int C, int HW,
                              long long E, int chunk_elems, int chunks, float* __restrict__ part) {
     __shared__ float red[4];
     const int c = blockIdx.y, chunk = blockIdx.x;
     const float mu = mean[c];
+    float istd = 0.f, gm = 0.f, bt = 0.f;
+    if (RELU == 2) { istd = 1.0f / sqrtf(var[c] + eps); gm = gamma[c]; bt = beta[c]; }
     const long long e0 = (long long)chunk * chunk_elems;
     long long e1 = e0 + chunk_elems;
     if (e1 > E) e1 = E;
@@ -159,10 +171,15 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
             const int i = (int)(e - n * HW);
             float4 g = *reinterpret_cast<const float4*>(dy + n * dy_nstride + coff + i);
             const float4 xv = *reinterpret_cast<const float4*>(x + n * x_nstride + coff + i);
-            if (RELU) {
+            if (RELU == 1) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + n * y_nstride + coff + i);
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            } else if (RELU == 2) {
+                g.x = bn_val(xv.x, mu, istd, gm, bt) > 0.f ? g.x : 0.f;
+                g.y = bn_val(xv.y, mu, istd, gm, bt) > 0.f ? g.y : 0.f;
+                g.z = bn_val(xv.z, mu, istd, gm, bt) > 0.f ? g.z : 0.f;
+                g.w = bn_val(xv.w, mu, istd, gm, bt) > 0.f ? g.w : 0.f;
             }
             s1 += (g.x + g.y) + (g.z + g.w);
             s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
@@ -172,9 +189,11 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
             const long long n = e / HW;
             const int i = (int)(e - n * HW);
             float g = dy[n * dy_nstride + coff + i];
-            if (RELU) g = y[n * y_nstride + coff + i] > 0.f ? g : 0.f;
+            const float xv = x[n * x_nstride + coff + i];
+            if (RELU == 1) g = y[n * y_nstride + coff + i] > 0.f ? g : 0.f;
+            else if (RELU == 2) g = bn_val(xv, mu, istd, gm, bt) > 0.f ? g : 0.f;
             s1 += g;
-            s2 += g * (x[n * x_nstride + coff + i] - mu);
+            s2 += g * (xv - mu);
         }
     }
     const float t1 = block_sum_256(s1, red);
@@ -199,12 +218,13 @@ __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict_
 }
 
 // ---- backward stage 2
-template <bool VEC, bool RELU>
+template <bool VEC, int RELU>
 __global__ void __launch_bounds__(kThreads)
 bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
                     const float* __restrict__ x, const float* __restrict__ y,
                     long long y_nstride, const float* __restrict__ mean,
-                    const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                    const float* __restrict__ var, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, float eps,
                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xmu,
                     float inv_count_host, const float* __restrict__ count_dev,
                     float* __restrict__ dx, float* __restrict__ dres, int C,
@@ -217,10 +237,12 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
     const float mu = mean[c];
     const float mean_dy = sum_dy[c] * inv_count;
     const float k = sum_dy_xmu[c] * inv_count * istd * istd;
-    const float gi = gamma[c] * istd;
+    const float gm = gamma[c];
+    const float gi = gm * istd;
+    const float bt = RELU == 2 ? beta[c] : 0.f;
     const float* dyr = dy + (long long)n * dy_nstride + (long long)c * HW;
     const float* xr = x + row * HW;
-    const float* yr = RELU ? y + (long long)n * y_nstride + (long long)c * HW : nullptr;
+    const float* yr = RELU == 1 ? y + (long long)n * y_nstride + (long long)c * HW : nullptr;
     float* dxr = dx + row * HW;
     float* drr = dres ? dres + row * HW : nullptr;
     const int i0 = chunk * cols_per_block;
@@ -230,10 +252,15 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
         for (int i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kThreads) {
             float4 g = *reinterpret_cast<const float4*>(dyr + i);
             const float4 xv = *reinterpret_cast<const float4*>(xr + i);
-            if (RELU) {
+            if (RELU == 1) {
                 const float4 yv = *reinterpret_cast<const float4*>(yr + i);
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            } else if (RELU == 2) {
+                g.x = bn_val(xv.x, mu, istd, gm, bt) > 0.f ? g.x : 0.f;
+                g.y = bn_val(xv.y, mu, istd, gm, bt) > 0.f ? g.y : 0.f;
+                g.z = bn_val(xv.z, mu, istd, gm, bt) > 0.f ? g.z : 0.f;
+                g.w = bn_val(xv.w, mu, istd, gm, bt) > 0.f ? g.w : 0.f;
             }
             float4 o;
             o.x = (g.x - mean_dy - (xv.x - mu) * k) * gi;
@@ -246,7 +273,8 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
     } else {
         for (int i = i0 + threadIdx.x; i < i1; i += kThreads) {
             float g = dyr[i];
-            if (RELU) g = yr[i] > 0.f ? g : 0.f;
+            if (RELU == 1) g = yr[i] > 0.f ? g : 0.f;
+            else if (RELU == 2) g = bn_val(xr[i], mu, istd, gm, bt) > 0.f ? g : 0.f;
             dxr[i] = (g - mean_dy - (xr[i] - mu) * k) * gi;
             if (drr) drr[i] = g;
         }
@@ -311,12 +339,15 @@ extern "C" int dcfp_bn_apply_f32(const float* x, const float* mean, const float*
 
 extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                                       const float* y, int64_t y_nstride, const float* mean,
-                                      int relu, int N, int C, int HW, float* sum_dy,
+                                      const float* var, const float* gamma, const float* beta,
+                                      float eps, int relu, int N, int C, int HW, float* sum_dy,
                                       float* sum_dy_xmu, void* workspace, size_t workspace_bytes,
                                       dcfp_stream_t stream) {
     if (!dy || !x || !mean || !sum_dy || !sum_dy_xmu || N <= 0 || C <= 0 || HW <= 0)
         return DCFP_E_BADDESC;
-    if (relu && !y) return DCFP_E_BADDESC;
+    if (relu < 0 || relu > 2) return DCFP_E_BADDESC;
+    if (relu == 1 && !y) return DCFP_E_BADDESC;
+    if (relu == 2 && (!var || !gamma || !beta)) return DCFP_E_BADDESC;
     if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
     if (y_nstride == 0) y_nstride = (int64_t)C * HW;
     const BnPlan p = bn_plan(N, C, HW);
@@ -325,14 +356,14 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
     float* part = static_cast<float*>(workspace);
     const long long E = (long long)N * HW;
     const bool vec = (HW % 4 == 0) && (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
-                     dcfp_aligned16(dy) && dcfp_aligned16(x) && (!relu || dcfp_aligned16(y));
+                     dcfp_aligned16(dy) && dcfp_aligned16(x) && (relu != 1 || dcfp_aligned16(y));
     dim3 grid(p.chunks, C);
 #define LAUNCH_RED(V, R)                                                                          \
     hipLaunchKernelGGL((bn_bwd_reduce_partial_kernel<V, R>), grid, dim3(kThreads), 0,             \
                        dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
-                       mean, C, HW, E, p.chunk_elems, p.chunks, part)
-    if (vec) { if (relu) LAUNCH_RED(true, true); else LAUNCH_RED(true, false); }
-    else     { if (relu) LAUNCH_RED(false, true); else LAUNCH_RED(false, false); }
+                       mean, var, gamma, beta, eps, C, HW, E, p.chunk_elems, p.chunks, part)
+    if (vec) { if (relu == 2) LAUNCH_RED(true, 2); else if (relu == 1) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
+    else     { if (relu == 2) LAUNCH_RED(false, 2); else if (relu == 1) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
     hipLaunchKernelGGL(bn_pair_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C,
                        p.chunks, part, sum_dy, sum_dy_xmu);
@@ -341,15 +372,15 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
 
 extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
                                      const float* y, int64_t y_nstride, const float* mean,
-                                     const float* var, const float* gamma, float eps,
-                                     const float* sum_dy, const float* sum_dy_xmu, float count,
-                                     const float* count_dev, int relu, float* dx,
+                                     const float* var, const float* gamma, const float* beta,
+                                     float eps, const float* sum_dy, const float* sum_dy_xmu,
+                                     float count, const float* count_dev, int relu, float* dx,
                                      float* d_residual, int N, int C, int HW,
                                      dcfp_stream_t stream) {
     if (!dy || !x || !mean || !var || !gamma || !sum_dy || !sum_dy_xmu || !dx || N <= 0 ||
         C <= 0 || HW <= 0 || (!count_dev && !(count > 0.f)))
         return DCFP_E_BADDESC;
-    if (relu && !y) return DCFP_E_BADDESC;
+    if (relu < 0 || relu > 2 || (relu == 1 && !y) || (relu == 2 && !beta)) return DCFP_E_BADDESC;
     if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
     if (y_nstride == 0) y_nstride = (int64_t)C * HW;
     const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
@@ -357,16 +388,16 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const bool vec = (HW % 4 == 0) && (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                      dcfp_aligned16(dy) && dcfp_aligned16(x) && dcfp_aligned16(dx) &&
-                     (!relu || dcfp_aligned16(y)) && (!d_residual || dcfp_aligned16(d_residual));
+                     (relu != 1 || dcfp_aligned16(y)) && (!d_residual || dcfp_aligned16(d_residual));
     const float inv_count = count > 0.f ? 1.0f / count : 0.f;
 #define LAUNCH_APP(V, R)                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R>), dim3((unsigned)blocks), dim3(kThreads), 0,    \
                        dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
-                       mean, var, gamma, eps, sum_dy, sum_dy_xmu, inv_count, count_dev, dx,       \
+                       mean, var, gamma, beta, eps, sum_dy, sum_dy_xmu, inv_count, count_dev, dx, \
                        d_residual, C,                                                             \
                        HW, colchunks, kColsPerBlock)
-    if (vec) { if (relu) LAUNCH_APP(true, true); else LAUNCH_APP(true, false); }
-    else     { if (relu) LAUNCH_APP(false, true); else LAUNCH_APP(false, false); }
+    if (vec) { if (relu == 2) LAUNCH_APP(true, 2); else if (relu == 1) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
+    else     { if (relu == 2) LAUNCH_APP(false, 2); else if (relu == 1) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
 #undef LAUNCH_APP
     DCFP_RETURN_LAUNCH();
 }

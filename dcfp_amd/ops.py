@@ -213,31 +213,33 @@ def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
     return y
 
 
-def bn_bwd_reduce(dy, x, y, mean, relu):
+def bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu):
+    """relu: 0 none, 1 mask from y, 2 mask re-derived from x (forward had no residual)."""
     N, Cc, H, W = x.shape
     dy, dns = _batch_strided(dy)
     L = _lib.lib()
     ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
     s1 = torch.empty(Cc, dtype=torch.float32, device=x.device)
     s2 = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu else 0.0)) * x.numel(), lambda: check(
-        L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean), int(relu),
-                                 N, Cc, H * W, _p(s1), _p(s2), _p(ws), ws.numel(), _stream()),
+    _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu == 1 else 0.0)) * x.numel(), lambda: check(
+        L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu == 1 else None, 0, _p(mean), _p(var),
+                                 _p(gamma), _p(beta), float(eps), int(relu), N, Cc, H * W, _p(s1), _p(s2),
+                                 _p(ws), ws.numel(), _stream()),
         "bn_bwd_reduce"))
     return s1, s2
 
 
-def bn_bwd_apply(dy, x, y, mean, var, gamma, eps, s1, s2, count, relu, want_residual):
+def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_residual):
     N, Cc, H, W = x.shape
     dy, dns = _batch_strided(dy)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual else None
-    nbytes = (12.0 + (4.0 if relu else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
+    nbytes = (12.0 + (4.0 if relu == 1 else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
     count_dev = count if isinstance(count, torch.Tensor) else None   # SyncBN: global count on device
     count_host = 0.0 if count_dev is not None else float(count)
     _timed("bn_bwd_apply", None, nbytes, lambda: check(
-        _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu else None, 0, _p(mean),
-                                         _p(var), _p(gamma), float(eps), _p(s1), _p(s2), count_host,
+        _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu == 1 else None, 0, _p(mean),
+                                         _p(var), _p(gamma), _p(beta), float(eps), _p(s1), _p(s2), count_host,
                                          _p(count_dev), int(relu), _p(dx), _p(dres), N, Cc, H * W,
                                          _stream()),
         "bn_bwd_apply"))
@@ -304,18 +306,21 @@ def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, t
     return y, (mean, var, count, group)
 
 
-def bn_backward_impl(dy, x, y, gamma, state, relu, training, eps, want_res):
+def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res):
     """Shared backward: returns (dx, dgamma, dbeta, dres).  dgamma/dbeta are this rank's sums
-    (the gradient all-reduce averages them); under SyncBN the sums entering dx are global."""
+    (the gradient all-reduce averages them); under SyncBN the sums entering dx are global.
+    `y` is only needed for the ReLU mask of a BN that had a residual input; otherwise the mask
+    is re-derived from x inside the kernels (pass y=None)."""
     mean, var, count, group = state
-    s1, s2 = bn_bwd_reduce(dy, x, y, mean, relu)
+    relu = (1 if y is not None else 2) if relu else 0
+    s1, s2 = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu)
     dgamma = s2 * torch.rsqrt(var + eps)
     dbeta = s1
     if training:
         r1, r2 = sync_bn_bwd_sums(s1, s2, group) if group is not None else (s1, s2)
     else:  # running statistics are constants: dx = g * gamma * istd
         r1 = torch.zeros_like(s1); r2 = torch.zeros_like(s2)
-    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, eps, r1, r2, count, relu, want_res)
+    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, r1, r2, count, relu, want_res)
     return dx, dgamma, dbeta, dres
 
 
@@ -333,7 +338,8 @@ class BatchNormActFn(torch.autograd.Function):
         y, state = bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu,
                                    training, momentum, eps, sync)
         mean, var, count, group = state
-        ctx.save_for_backward(x, y if relu else None, mean, var, gamma,
+        # y is saved only where the ReLU mask cannot be re-derived from x (residual input)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var, gamma, beta,
                               count if isinstance(count, torch.Tensor) else None)
         ctx.cfg = (relu, training, eps, None if isinstance(count, torch.Tensor) else count, group,
                    residual is not None)
@@ -341,11 +347,11 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, gamma, count_t = ctx.saved_tensors
+        x, y, mean, var, gamma, beta, count_t = ctx.saved_tensors
         relu, training, eps, count, group, has_res = ctx.cfg
         state = (mean, var, count_t if count_t is not None else count, group)
         need_res = has_res and ctx.needs_input_grad[5]
-        dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, state, relu, training, eps, need_res)
+        dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, need_res)
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
@@ -391,18 +397,18 @@ class BottleneckFn(torch.autograd.Function):
         stride, dil, training, eps = ctx.cfg
         st1, st2, st3, std = ctx.states
         # bn3 (+residual, ReLU): gradient of conv3's output and of the residual branch
-        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, st3, True, training[2], eps[2], True)
+        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], True)
         d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
         dw3, _ = conv2d_wgrad(d_c3, y2, tuple(w3.shape), 1, 0, 1)
-        d_c2, dg2, db2, _ = bn_backward_impl(d_y2, c2, y2, g2, st2, True, training[1], eps[1], False)
+        d_c2, dg2, db2, _ = bn_backward_impl(d_y2, c2, None, g2, b2, st2, True, training[1], eps[1], False)
         d_y1 = conv2d_dgrad(d_c2, w2, tuple(y1.shape), stride, dil, dil)
         dw2, _ = conv2d_wgrad(d_c2, y1, tuple(w2.shape), stride, dil, dil)
-        d_c1, dg1, db1, _ = bn_backward_impl(d_y1, c1, y1, g1, st1, True, training[0], eps[0], False)
+        d_c1, dg1, db1, _ = bn_backward_impl(d_y1, c1, None, g1, b1, st1, True, training[0], eps[0], False)
         dw1, _ = conv2d_wgrad(d_c1, x, tuple(w1.shape), 1, 0, 1)
         grads = [dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3]
         if ctx.has_ds:
             wd, gd, bd = tensors[9:]
-            d_cd, dgd, dbd, _ = bn_backward_impl(d_res, cd, None, gd, std, False, training[3], eps[3], False)
+            d_cd, dgd, dbd, _ = bn_backward_impl(d_res, cd, None, gd, bd, std, False, training[3], eps[3], False)
             dwd, _ = conv2d_wgrad(d_cd, x, tuple(wd.shape), stride, 0, 1)
             grads += [dwd, dgd, dbd]
             dx = conv2d_dgrad(d_cd, wd, tuple(x.shape), stride, 0, 1) if ctx.needs_input_grad[0] else None

@@ -99,12 +99,16 @@ int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
                       const float* gamma, const float* beta, float eps,
                       const float* residual, int relu, float* y, int64_t y_nstride,
                       int N, int C, int HW, dcfp_stream_t stream);
-/* Backward stage 1: with g = dy * (relu ? y>0 : 1):
+/* Backward stage 1: with g = dy * mask:
  *   sum_dy[c] = sum g ;  sum_dy_xmu[c] = sum g*(x-mean[c])
  * (dbeta = sum_dy; dgamma = sum_dy_xmu * rsqrt(var+eps): the per-filter statistic
- * that feeds the EIC score, pruners/dcfp_pruner.py:18).  y may be NULL iff !relu. */
+ * that feeds the EIC score, pruners/dcfp_pruner.py:18).
+ * relu: 0 no ReLU (mask = 1); 1 mask = (y > 0) read from the saved output y;
+ *       2 mask re-derived from x with the forward's own expression (only valid when the
+ *         forward had no residual input; needs var/gamma/beta, y may be NULL). */
 int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                            const float* y, int64_t y_nstride, const float* mean,
+                           const float* var, const float* gamma, const float* beta, float eps,
                            int relu, int N, int C, int HW,
                            float* sum_dy, float* sum_dy_xmu,
                            void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
@@ -113,7 +117,7 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
  * one float) then overrides `count` without a host round trip.  d_residual (nullable) = g. */
 int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
                           const float* y, int64_t y_nstride, const float* mean,
-                          const float* var, const float* gamma, float eps,
+                          const float* var, const float* gamma, const float* beta, float eps,
                           const float* sum_dy, const float* sum_dy_xmu, float count,
                           const float* count_dev,
                           int relu, float* dx, float* d_residual,
