@@ -238,6 +238,35 @@ def ohem_cases():
     np.savez_compressed(os.path.join(OUT, "ohem_threshold.npz"), **rec)
 
 
+def flops_golden():
+    """utils/flops_counter.get_model_complexity_info on the full and the pruned v3-R50
+    (prune.py:77-78,112-113), input (3,257,257) to keep the CPU forward short."""
+    from utils.flops_counter import get_model_complexity_info
+    import copy
+    rec = {}
+    for tag, bb in (("v3_r50", "resnet50"), ("v3_r101", "resnet101")):
+        cls = networks.deeplabv3.Seg_Model
+        m = cls(backbone=bb, backbone_para=dict(BB_PARA), model_para={}, num_classes=19, align_corner=True,
+                criterion=None, deepsup=False)
+        f, pcount = get_model_complexity_info(m, (3, 257, 257), print_per_layer_stat=False, as_strings=False)
+        fs, ps = get_model_complexity_info(m, (3, 257, 257), print_per_layer_stat=False)
+        rec[f"flops:{tag}"] = np.array(float(f)); rec[f"params:{tag}"] = np.array(float(pcount))
+        rec[f"str:{tag}"] = np.array([fs, ps])
+    # pruned model at global_percent 0.5
+    m = build_ref("deeplabv3", "resnet50", True, torch.float32)
+    m.criterion = None
+    torch.save({"eic": synthetic_scores(m)}, "/tmp/_golden_score.pth")
+    pruner = dp.DCFPPruner(global_percent=0.5, layer_keep=0.02, score_file="/tmp/_golden_score.pth")
+    pruned, channel_cfg = pruner.prune_model(copy.deepcopy(m), except_start_keys=["conv_deepsup"])
+    slim = networks.deeplabv3.Seg_Model(backbone="resnet50", backbone_para=dict(BB_PARA), model_para={},
+                                        num_classes=19, align_corner=True, criterion=None, deepsup=False)
+    pruners.init_pruned_model(slim, channel_cfg)
+    f, pcount = get_model_complexity_info(slim, (3, 257, 257), print_per_layer_stat=False, as_strings=False)
+    rec["flops:v3_r50_gp50"] = np.array(float(f)); rec["params:v3_r50_gp50"] = np.array(float(pcount))
+    np.savez_compressed(os.path.join(OUT, "flops.npz"), **rec)
+    print("wrote flops golden", {k: (v.tolist() if v.dtype.kind != "U" else v.tolist()) for k, v in rec.items()})
+
+
 def lr_schedule():
     rec = {"poly": np.array([ref_optimizer.lr_poly(0.01, i, 4000, 0.9) for i in (0, 1, 1999, 3999)]),
            "warm": np.array([ref_optimizer.lr_warmup(0.01, i, 1000) for i in (0, 1, 500, 999, 1000)])}
@@ -247,7 +276,7 @@ def lr_schedule():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["eic", "lr", "ohem", "simple", "v3r50", "v3r101", "prune"]
+    which = sys.argv[1:] or ["eic", "lr", "ohem", "simple", "v3r50", "v3r101", "prune", "flops"]
     if "eic" in which:
         eic_trajectory()
     if "lr" in which:
@@ -262,3 +291,5 @@ if __name__ == "__main__":
         whole_model("v3_r101_2x65x65", "deeplabv3", "resnet101", 2, 65, 65, True)
     if "prune" in which:
         masks_and_surgery()
+    if "flops" in which:
+        flops_golden()

@@ -222,3 +222,28 @@ def test_pruned_model_runs_on_hip(cuda):
     k = "backbone.layer2.0.bn2"
     a = dict(slim.named_modules())[k].weight.grad.cpu().double(); b = osd[k + ".weight"].grad.double()
     assert ((a - b).norm() / b.norm()).item() < 5e-2
+
+
+def test_train_score_prune_finetune_pipeline(cuda, tmp_path):
+    """Config (5) end to end with the drivers: pretrain+score (tools/train.py) -> offline prune
+    loop to a FLOPs target (tools/prune.py) -> fine-tune steps on the slim model with
+    --channel-cfg/--resume, all on the HIP path except the offline prune (CPU, like the reference)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import importlib
+    train = importlib.import_module("train"); prune = importlib.import_module("prune")
+    d1, d2, d3 = str(tmp_path / "pre"), str(tmp_path / "pr"), str(tmp_path / "ft")
+    common = ["--model", "deeplabv3", "--backbone", "resnet50", "--batch-size", "2", "--input-size", "65,65",
+              "--backbone-para", '{"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": false}']
+    train.main(common + ["--num-steps", "3", "--prune-type", "dcfp", "--snapshot-dir", d1])
+    assert os.path.exists(d1 + "/score.pth") and os.path.exists(d1 + "/CS_scenes_3.pth")
+    score = torch.load(d1 + "/score.pth")["eic"]
+    assert len(score) == 62 and all(v.dtype == torch.float32 for v in score.values())
+    gp = prune.main(["--model", "deeplabv3", "--backbone", "resnet50", "--backbone-para", common[-1],
+                     "--model-path", d1 + "/CS_scenes_3.pth", "--score-path", d1 + "/score.pth",
+                     "--save-path", d2, "--prune-ratio", "0.4"])
+    assert 0.5 <= gp < 1.0 and os.path.exists(d2 + "/channel_cfg.pth")
+    train.main(common + ["--num-steps", "2", "--channel-cfg", d2 + "/channel_cfg.pth", "--resume", d2 + "/pruned.pth",
+                         "--snapshot-dir", d3])
+    sd = torch.load(d3 + "/CS_scenes_2.pth")
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())

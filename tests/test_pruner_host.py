@@ -72,3 +72,32 @@ def test_prune_model_matches_reference(gp, tmp_path):
     outs, _, _ = omodel.seg_forward(omodel.clone_state(slim.state_dict(), requires_grad=False),
                                     fill.closed_form_input(2, 33, 33), ocfg, None, training=False)
     assert np.abs(outs[0].numpy() - g["slim_logits"]).max() < 1e-5
+
+
+def test_flops_counter_matches_reference():
+    """Static complexity counter vs utils/flops_counter.get_model_complexity_info of the reference
+    (full R50 / R101 models and the global_percent=0.5 pruned model)."""
+    path = os.path.join(G, "flops.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden missing")
+    g = np.load(path)
+    from dcfp_amd import networks, pruners
+    from dcfp_amd.pruners.dcfp_pruner import DCFPPruner
+    from dcfp_amd.utils.flops_counter import get_model_complexity_info
+    import tempfile
+    for tag, bb in (("v3_r50", "resnet50"), ("v3_r101", "resnet101")):
+        m = networks.deeplabv3.Seg_Model(backbone=bb, backbone_para=dict(BB), num_classes=19, align_corner=True,
+                                         deepsup=False)
+        f, p = get_model_complexity_info(m, (3, 257, 257), print_per_layer_stat=False, as_strings=False)
+        assert float(f) == float(g[f"flops:{tag}"]) and float(p) == float(g[f"params:{tag}"])
+        assert list(get_model_complexity_info(m, (3, 257, 257), print_per_layer_stat=False)) == g[f"str:{tag}"].tolist()
+    m = build()
+    with tempfile.TemporaryDirectory() as d:
+        torch.save({"eic": synthetic_scores(m)}, d + "/score.pth")
+        pr = DCFPPruner(global_percent=0.5, layer_keep=0.02, score_file=d + "/score.pth")
+        _, cfg = pr.prune_model(copy.deepcopy(m), except_start_keys=["conv_deepsup"])
+    slim = networks.deeplabv3.Seg_Model(backbone="resnet50", backbone_para=dict(BB), num_classes=19,
+                                        align_corner=True, deepsup=False)
+    pruners.init_pruned_model(slim, cfg)
+    f, p = get_model_complexity_info(slim, (3, 257, 257), print_per_layer_stat=False, as_strings=False)
+    assert float(f) == float(g["flops:v3_r50_gp50"]) and float(p) == float(g["params:v3_r50_gp50"])
