@@ -67,6 +67,11 @@ SIGNATURES = {
                                       _Z, _P]),
     "dcfp_upsample_ce_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dcfp_ohem_zoom_gt_prob_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "dcfp_upsample_margin_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dcfp_maxfilter2d_s1_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dcfp_upsample_wce_workspace_bytes": (_Z, [_I, _I, _I]),
+    "dcfp_upsample_wce_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "dcfp_upsample_wce_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dcfp_eic_update_f32": (_I, [_P, _I, _F, _F, _P]),
     "dcfp_sgd_momentum_f32": (_I, [_P, _I, _L, _F, _F, _I, _P]),
 }

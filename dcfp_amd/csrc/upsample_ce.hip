@@ -289,6 +289,170 @@ ohem_zoom_kernel(const float* __restrict__ logits, const long long* __restrict__
     }
 }
 
+// ---- GSRL (loss/criterion.py:77-101): margin map, k x k stride-1 max filter, per-pixel-weighted CE
+// margin[pix] = p1 - p2 (two largest softmax probabilities of the interpolated logits)
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_margin_kernel(const float* __restrict__ logits, int N, int C, int h, int w, int H, int W,
+                       float sh, float sw, float* __restrict__ margin) {
+    const long long total = (long long)N * H * W;
+    const long long plane = (long long)h * w;
+    for (long long pix = (long long)blockIdx.x * kThreads + threadIdx.x; pix < total;
+         pix += (long long)gridDim.x * kThreads) {
+        const int X = (int)(pix % W);
+        const long long t = pix / W;
+        const int Y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Lerp Lh = lerp_of<ALIGN>(Y, sh, h), Lw = lerp_of<ALIGN>(X, sw, w);
+        const int o00 = Lh.i0 * w + Lw.i0, o01 = Lh.i0 * w + Lw.i1;
+        const int o10 = Lh.i1 * w + Lw.i0, o11 = Lh.i1 * w + Lw.i1;
+        const float* base = logits + (long long)n * C * plane;
+        float m1 = -INFINITY, m2 = -INFINITY, s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* p = base + c * plane;
+            const float z = Lh.l0 * (Lw.l0 * p[o00] + Lw.l1 * p[o01]) +
+                            Lh.l1 * (Lw.l0 * p[o10] + Lw.l1 * p[o11]);
+            if (z > m1) {
+                s = s * expf(m1 - z) + 1.f;
+                m2 = m1;
+                m1 = z;
+            } else {
+                s += expf(z - m1);
+                m2 = z > m2 ? z : m2;
+            }
+        }
+        // p1 = exp(m1 - lse) = 1/s ; p2 = exp(m2 - m1)/s
+        margin[pix] = (1.f - (C > 1 ? expf(m2 - m1) : 0.f)) / s;
+    }
+}
+
+// y = max over the k x k window (stride 1, pad k/2, -inf padding) of a [planes,H,W] map
+__global__ void __launch_bounds__(kThreads)
+maxfilter_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int H, int W,
+                 int k) {
+    const int r = k / 2;
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int X = (int)(idx % W);
+        const long long t = idx / W;
+        const int Y = (int)(t % H);
+        const float* xp = x + (t / H) * (long long)H * W;
+        const int y0 = Y - r < 0 ? 0 : Y - r, y1 = Y + (k - 1 - r) > H - 1 ? H - 1 : Y + (k - 1 - r);
+        const int x0 = X - r < 0 ? 0 : X - r, x1 = X + (k - 1 - r) > W - 1 ? W - 1 : X + (k - 1 - r);
+        float best = -INFINITY;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                const float v = xp[yy * W + xx];
+                best = (v > best || v != v) ? v : best;
+            }
+        y[idx] = best;
+    }
+}
+
+// per-image sums  out[n] = (sum_pix w*ce, sum_pix w)  with w = pix_weight (0 where ignored)
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_wce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                        const float* __restrict__ pw, int ignore_index, int C, int h, int w, int H,
+                        int W, float sh, float sw, float* __restrict__ lse_out,
+                        float* __restrict__ part /* [N][gridDim.x][2] */) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const long long HWl = (long long)H * W;
+    const long long plane = (long long)h * w;
+    const float* base = logits + (long long)n * C * plane;
+    float a = 0.f, b = 0.f;
+    for (long long q = (long long)blockIdx.x * kThreads + threadIdx.x; q < HWl;
+         q += (long long)gridDim.x * kThreads) {
+        const int X = (int)(q % W), Y = (int)(q / W);
+        const long long pix = n * HWl + q;
+        const Lerp Lh = lerp_of<ALIGN>(Y, sh, h), Lw = lerp_of<ALIGN>(X, sw, w);
+        const int o00 = Lh.i0 * w + Lw.i0, o01 = Lh.i0 * w + Lw.i1;
+        const int o10 = Lh.i1 * w + Lw.i0, o11 = Lh.i1 * w + Lw.i1;
+        const long long label = labels[pix];
+        float m = -INFINITY, s = 0.f, zl = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* p = base + c * plane;
+            const float z = Lh.l0 * (Lw.l0 * p[o00] + Lw.l1 * p[o01]) +
+                            Lh.l1 * (Lw.l0 * p[o10] + Lw.l1 * p[o11]);
+            if (z > m) { s = s * expf(m - z) + 1.f; m = z; } else { s += expf(z - m); }
+            if (c == label) zl = z;
+        }
+        const float lse = m + logf(s);
+        if (lse_out) lse_out[pix] = lse;
+        const float wgt = pw[pix];
+        if (label != ignore_index) a += wgt * (lse - zl);   // CE(reduction='none') is 0 where ignored
+        b += wgt;
+    }
+    const float t1 = block_sum_256(a, red);
+    const float t2 = block_sum_256(b, red);
+    if (threadIdx.x == 0) {
+        part[((long long)n * gridDim.x + blockIdx.x) * 2 + 0] = t1;
+        part[((long long)n * gridDim.x + blockIdx.x) * 2 + 1] = t2;
+    }
+}
+
+__global__ void wce_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+    const int n = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblocks; ++k) {
+        a += (double)part[((long long)n * nblocks + k) * 2];
+        b += (double)part[((long long)n * nblocks + k) * 2 + 1];
+    }
+    out[2 * n] = (float)a;
+    out[2 * n + 1] = (float)b;
+}
+
+// dlogits[n,c,i,j] = gs[n] * sum_pix wt * pw[pix] * (softmax - onehot)   (gather form)
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_wce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                        const float* __restrict__ pw, int ignore_index, int N, int C, int h, int w,
+                        int H, int W, float sh, float sw, const float* __restrict__ lse,
+                        const float* __restrict__ gs, float* __restrict__ dlogits) {
+    const long long total = (long long)N * C * h * w;
+    for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kThreads) {
+        const int j = (int)(idx % w);
+        long long t = idx / w;
+        const int i = (int)(t % h);
+        t /= h;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        const float* p = logits + ((long long)n * C + c) * h * w;
+        const long long* lab = labels + (long long)n * H * W;
+        const float* ls = lse + (long long)n * H * W;
+        const float* wp = pw + (long long)n * H * W;
+        int ylo, yhi, xlo, xhi;
+        dst_range<ALIGN>(i, sh, H, ylo, yhi);
+        dst_range<ALIGN>(j, sw, W, xlo, xhi);
+        float acc = 0.f;
+        for (int Y = ylo; Y <= yhi; ++Y) {
+            const Lerp Lh = lerp_of<ALIGN>(Y, sh, h);
+            const float wy = tap_weight(Lh, i);
+            if (wy == 0.f) continue;
+            const float* r0 = p + Lh.i0 * w;
+            const float* r1 = p + Lh.i1 * w;
+            float row = 0.f;
+            for (int X = xlo; X <= xhi; ++X) {
+                const Lerp Lw = lerp_of<ALIGN>(X, sw, w);
+                const float wx = tap_weight(Lw, j);
+                if (wx == 0.f) continue;
+                const long long q = (long long)Y * W + X;
+                const long long label = lab[q];
+                const float wgt = wp[q];
+                if (label == ignore_index || wgt == 0.f) continue;
+                const float z = Lh.l0 * (Lw.l0 * r0[Lw.i0] + Lw.l1 * r0[Lw.i1]) +
+                                Lh.l1 * (Lw.l0 * r1[Lw.i0] + Lw.l1 * r1[Lw.i1]);
+                row += wx * wgt * (expf(z - ls[q]) - (label == c ? 1.f : 0.f));
+            }
+            acc += wy * row;
+        }
+        dlogits[idx] = acc * gs[n];
+    }
+}
+
 inline unsigned stream_grid(long long total) {
     long long b = (total + kThreads - 1) / kThreads;
     if (b > 256 * 16) b = 256 * 16;
@@ -401,5 +565,85 @@ extern "C" int dcfp_ohem_zoom_gt_prob_f32(const float* logits, const int64_t* la
     else
         hipLaunchKernelGGL(ohem_zoom_kernel<false>, dim3(stream_grid(total)), dim3(kThreads), 0,
                            dcfp_s(stream), logits, lab, lse, N, C, h, w, H, W, sh, sw, H8, W8, pred8, lab8);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_upsample_margin_f32(const float* logits, int N, int C, int h, int w, int H, int W,
+                                        int align_corners, float* margin, dcfp_stream_t stream) {
+    if (!logits || !margin || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
+    const long long total = (long long)N * H * W;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_margin_kernel<true>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, N, C, h, w, H, W, sh, sw, margin);
+    else
+        hipLaunchKernelGGL(upsample_margin_kernel<false>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, N, C, h, w, H, W, sh, sw, margin);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_maxfilter2d_s1_f32(const float* x, float* y, int planes, int H, int W, int k,
+                                       dcfp_stream_t stream) {
+    if (!x || !y || planes <= 0 || H <= 0 || W <= 0 || k <= 0 || (k & 1) == 0) return DCFP_E_BADDESC;
+    const long long total = (long long)planes * H * W;
+    hipLaunchKernelGGL(maxfilter_kernel, dim3(stream_grid(total)), dim3(kThreads), 0, dcfp_s(stream), x, y,
+                       total, H, W, k);
+    DCFP_RETURN_LAUNCH();
+}
+
+constexpr int kWceBlocks = 512;   // per image
+
+extern "C" size_t dcfp_upsample_wce_workspace_bytes(int N, int H, int W) {
+    (void)H; (void)W;
+    return (size_t)(N > 0 ? N : 0) * kWceBlocks * 2 * sizeof(float);
+}
+
+extern "C" int dcfp_upsample_wce_fwd_f32(const float* logits, const int64_t* labels,
+                                         const float* pix_weight, int ignore_index, int N, int C, int h,
+                                         int w, int H, int W, int align_corners, float* lse,
+                                         float* out_per_image, void* workspace, size_t workspace_bytes,
+                                         dcfp_stream_t stream) {
+    if (!logits || !labels || !pix_weight || !out_per_image || N <= 0 || C <= 0 || h <= 0 || w <= 0 ||
+        H <= 0 || W <= 0 || N > 65535)
+        return DCFP_E_BADDESC;
+    if (!workspace || workspace_bytes < (size_t)N * kWceBlocks * 2 * sizeof(float)) return DCFP_E_WORKSPACE;
+    long long blocks = ((long long)H * W + kThreads - 1) / kThreads;
+    if (blocks > kWceBlocks) blocks = kWceBlocks;
+    float* part = static_cast<float*>(workspace);
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    const long long* lab = reinterpret_cast<const long long*>(labels);
+    dim3 grid((unsigned)blocks, (unsigned)N);
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_wce_fwd_kernel<true>, grid, dim3(kThreads), 0, dcfp_s(stream), logits, lab,
+                           pix_weight, ignore_index, C, h, w, H, W, sh, sw, lse, part);
+    else
+        hipLaunchKernelGGL(upsample_wce_fwd_kernel<false>, grid, dim3(kThreads), 0, dcfp_s(stream), logits, lab,
+                           pix_weight, ignore_index, C, h, w, H, W, sh, sw, lse, part);
+    hipLaunchKernelGGL(wce_final_kernel, dim3((unsigned)N), dim3(64), 0, dcfp_s(stream), part, (int)blocks,
+                       out_per_image);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_upsample_wce_bwd_f32(const float* logits, const int64_t* labels,
+                                         const float* pix_weight, int ignore_index, int N, int C, int h,
+                                         int w, int H, int W, int align_corners, const float* lse,
+                                         const float* grad_scale_per_image, float* dlogits,
+                                         dcfp_stream_t stream) {
+    if (!logits || !labels || !pix_weight || !lse || !grad_scale_per_image || !dlogits || N <= 0 ||
+        C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return DCFP_E_BADDESC;
+    const long long total = (long long)N * C * h * w;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    const long long* lab = reinterpret_cast<const long long*>(labels);
+    long long blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_wce_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, pix_weight, ignore_index, N, C, h, w, H, W, sh, sw,
+                           lse, grad_scale_per_image, dlogits);
+    else
+        hipLaunchKernelGGL(upsample_wce_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, lab, pix_weight, ignore_index, N, C, h, w, H, W, sh, sw,
+                           lse, grad_scale_per_image, dlogits);
     DCFP_RETURN_LAUNCH();
 }

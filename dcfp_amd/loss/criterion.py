@@ -24,8 +24,9 @@ def build_criterion(loss_type, dataset, loss_para):
         cls = CriterionDSN
     elif loss_type == "ohem":
         cls = CriterionOhemDSN
+    elif loss_type == "gsrl":
+        cls = CriterionGsrlDSN
     else:
-        # 'gsrl' (criterion.py:77-101) belongs to the fine-tune stage: SURVEY.md §8(f) rank 3
         raise NotImplementedError(loss_type)
     return cls(dataset=dataset, **loss_para)
 
@@ -83,3 +84,37 @@ class CriterionDSN(nn.Module):
             preds, target = [preds["pred"], preds["deepsup"]], target["ori"]
         size = target.shape[-2:]
         return self.forward_lowres(list(preds), target, size, True)
+
+
+class CriterionGsrlDSN(nn.Module):
+    """Fine-tune loss of DCFP (criterion.py:77-101): per-pixel balance weights, dilated by a k x k
+    max filter and multiplied by the calibration factor 1 + gamma*(1 - (p1 - p2)) of the main
+    head's top-2 softmax margin, weight CE(main) and CE(deep supervision); each is normalised
+    per image by its weight sum and averaged over the batch.
+    labels: {'ori': int64 [N,H,W], 'weight': float [N,H,W]}."""
+
+    def __init__(self, dataset=None, ds_weight=0.4, k=9, gamma=9, **kwargs):
+        super().__init__()
+        self.k = k
+        self.gamma = gamma
+        self.ignore_index = dataset.ignore_label
+        self.ds_weight = ds_weight
+
+    def _term(self, logits, ori, weight, size, align_corner):
+        out = ops.upsample_weighted_ce(logits, ori, weight, size, align_corner, self.ignore_index)
+        return torch.mean(out[:, 0] / (out[:, 1] + 1e-8))
+
+    def forward_lowres(self, preds, labels, size, align_corner):
+        ori = labels["ori"]
+        with torch.no_grad():
+            weight = ops.maxfilter2d(labels["weight"].to(torch.float32), self.k)
+            margin = ops.upsample_margin(preds[0].detach(), size, align_corner)
+            weight = (1 + self.gamma * (1 - margin)) * weight
+            weight[ori == self.ignore_index] = 0.0
+        loss = self._term(preds[0], ori, weight, size, align_corner)
+        if len(preds) >= 2:
+            loss = loss + self.ds_weight * self._term(preds[1], ori, weight, size, align_corner)
+        return {"loss": loss}
+
+    def forward(self, preds, labels):
+        return self.forward_lowres(list(preds), labels, labels["ori"].shape[-2:], True)

@@ -647,3 +647,64 @@ def upsample_cross_entropy(logits, labels, size, align_corners, ignore_index=255
         pixel_keep = pixel_keep.to(torch.uint8).contiguous()
     return UpsampleCEFn.apply(logits, labels, int(size[0]), int(size[1]), align_corners,
                               ignore_index, pixel_keep)
+
+
+# ------------------------------------------------------------------ GSRL pieces
+def upsample_margin(logits, size, align_corners):
+    """p1 - p2 of softmax(F.interpolate(logits, size)) per pixel, [N,H,W]."""
+    _require(logits, "logits")
+    logits = logits.contiguous()
+    N, Cc, h, w = logits.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
+    check(_lib.lib().dcfp_upsample_margin_f32(_p(logits), N, Cc, h, w, H, W, int(bool(align_corners)),
+                                              _p(out), _stream()), "upsample_margin")
+    return out
+
+
+def maxfilter2d(x, k):
+    """F.max_pool2d(x[:,None], k, stride=1, padding=k//2)[:,0] for a [N,H,W] map."""
+    _require(x, "x")
+    x = x.contiguous()
+    N, H, W = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().dcfp_maxfilter2d_s1_f32(_p(x), _p(y), N, H, W, int(k), _stream()), "maxfilter2d")
+    return y
+
+
+class UpsampleWCEFn(torch.autograd.Function):
+    """Per-image (sum w*CE, sum w) of the bilinearly upsampled logits with per-pixel weights w
+    (loss/criterion.py:94-99), fused like UpsampleCEFn."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, pix_weight, H, W, align_corners, ignore_index):
+        _require(logits, "logits"); _require(pix_weight, "pix_weight")
+        logits = logits.contiguous(); labels = labels.contiguous(); pix_weight = pix_weight.contiguous()
+        N, Cc, h, w = logits.shape
+        L = _lib.lib()
+        ws = _workspace("wce", L.dcfp_upsample_wce_workspace_bytes(N, H, W), logits.device)
+        lse = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
+        out = torch.empty((N, 2), dtype=torch.float32, device=logits.device)
+        check(L.dcfp_upsample_wce_fwd_f32(_p(logits), _p(labels), _p(pix_weight), int(ignore_index), N, Cc,
+                                          h, w, H, W, int(bool(align_corners)), _p(lse), _p(out), _p(ws),
+                                          ws.numel(), _stream()), "upsample_wce_fwd")
+        ctx.save_for_backward(logits, labels, pix_weight, lse)
+        ctx.cfg = (H, W, int(bool(align_corners)), int(ignore_index))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, pix_weight, lse = ctx.saved_tensors
+        H, W, ac, ignore = ctx.cfg
+        N, Cc, h, w = logits.shape
+        gs = gout[:, 0].contiguous().to(torch.float32)
+        dl = torch.empty_like(logits)
+        check(_lib.lib().dcfp_upsample_wce_bwd_f32(_p(logits), _p(labels), _p(pix_weight), ignore, N, Cc, h, w,
+                                                   H, W, ac, _p(lse), _p(gs), _p(dl), _stream()),
+              "upsample_wce_bwd")
+        return dl, None, None, None, None, None, None
+
+
+def upsample_weighted_ce(logits, labels, pix_weight, size, align_corners, ignore_index=255):
+    return UpsampleWCEFn.apply(logits, labels, pix_weight, int(size[0]), int(size[1]), align_corners,
+                               ignore_index)

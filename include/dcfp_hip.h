@@ -186,6 +186,28 @@ int dcfp_ohem_zoom_gt_prob_f32(const float* logits, const int64_t* labels, const
                                int H8, int W8, float* pred8, int32_t* lab8,
                                dcfp_stream_t stream);
 
+/* GSRL fine-tune loss (loss/criterion.py:77-101), fused the same way as the CE above:
+ *   margin[pix]  = p1 - p2, the two largest softmax probabilities of the interpolated logits
+ *                  (replaces softmax + sort over the full-resolution tensor, :89-91);
+ *   maxfilter    = F.max_pool2d(weight, k, stride=1, padding=k/2) of the balance weights (:88);
+ *   wce fwd/bwd  = CE(reduction='none') * pix_weight, summed per image:
+ *                  out_per_image[n] = (sum w*ce, sum w); bwd scales image n by
+ *                  grad_scale_per_image[n] (:94-99: per-image normalisation, mean over images). */
+int dcfp_upsample_margin_f32(const float* logits, int N, int C, int h, int w, int H, int W,
+                             int align_corners, float* margin, dcfp_stream_t stream);
+int dcfp_maxfilter2d_s1_f32(const float* x, float* y, int planes, int H, int W, int k,
+                            dcfp_stream_t stream);
+size_t dcfp_upsample_wce_workspace_bytes(int N, int H, int W);
+int dcfp_upsample_wce_fwd_f32(const float* logits, const int64_t* labels, const float* pix_weight,
+                              int ignore_index, int N, int C, int h, int w, int H, int W,
+                              int align_corners, float* lse, float* out_per_image,
+                              void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
+int dcfp_upsample_wce_bwd_f32(const float* logits, const int64_t* labels, const float* pix_weight,
+                              int ignore_index, int N, int C, int h, int w, int H, int W,
+                              int align_corners, const float* lse,
+                              const float* grad_scale_per_image, float* dlogits,
+                              dcfp_stream_t stream);
+
 /* ------------------------------------------------------------- EIC score
  * dcfp_pruning.step (pruners/dcfp_pruner.py:15-20), all scored BN layers in one
  * launch.  table: device array of n_layers records; eic is updated in place:

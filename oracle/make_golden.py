@@ -267,6 +267,30 @@ def flops_golden():
     print("wrote flops golden", {k: (v.tolist() if v.dtype.kind != "U" else v.tolist()) for k, v in rec.items()})
 
 
+def gsrl_golden():
+    """CriterionGsrlDSN (loss/criterion.py:77-101) on interpolated low-resolution logits."""
+    import torch.nn.functional as F
+    crit = build_criterions("gsrl", _DS(), {"ds_weight": 0.4})
+    rec = {}
+    for tag, (n, c, h, w, H, W, align) in {"a": (2, 19, 9, 13, 65, 97, True), "b": (2, 7, 8, 8, 33, 33, False)}.items():
+        i = torch.arange(n * c * h * w, dtype=torch.float64)
+        z0 = (2.0 * torch.cos(0.37 * i) + torch.cos(2.3 * i + 1)).reshape(n, c, h, w).float().requires_grad_(True)
+        z1 = (1.5 * torch.cos(0.91 * i + 2)).reshape(n, c, h, w).float().requires_grad_(True)
+        lab = fill.closed_form_labels(n, H, W, num_classes=c)
+        j = torch.arange(n * H * W, dtype=torch.float64)
+        wgt = (1.0 + 0.8 * torch.cos(0.05 * j) * (j % 7 == 0)).reshape(n, H, W).float()
+        p0 = F.interpolate(z0, size=(H, W), mode="bilinear", align_corners=align)
+        p1 = F.interpolate(z1, size=(H, W), mode="bilinear", align_corners=align)
+        loss = crit([p0, p1], {"ori": lab, "weight": wgt})["loss"]
+        loss.backward()
+        rec[f"z0:{tag}"] = z0.detach().numpy(); rec[f"z1:{tag}"] = z1.detach().numpy()
+        rec[f"lab:{tag}"] = lab.numpy(); rec[f"wgt:{tag}"] = wgt.numpy()
+        rec[f"loss:{tag}"] = np.array(loss.item()); rec[f"g0:{tag}"] = z0.grad.numpy(); rec[f"g1:{tag}"] = z1.grad.numpy()
+        rec[f"meta:{tag}"] = np.array([H, W, int(align)])
+        print("gsrl", tag, loss.item())
+    np.savez_compressed(os.path.join(OUT, "gsrl.npz"), **rec)
+
+
 def lr_schedule():
     rec = {"poly": np.array([ref_optimizer.lr_poly(0.01, i, 4000, 0.9) for i in (0, 1, 1999, 3999)]),
            "warm": np.array([ref_optimizer.lr_warmup(0.01, i, 1000) for i in (0, 1, 500, 999, 1000)])}
@@ -276,7 +300,7 @@ def lr_schedule():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["eic", "lr", "ohem", "simple", "v3r50", "v3r101", "prune", "flops"]
+    which = sys.argv[1:] or ["eic", "lr", "ohem", "simple", "v3r50", "v3r101", "prune", "flops", "gsrl"]
     if "eic" in which:
         eic_trajectory()
     if "lr" in which:
@@ -293,3 +317,5 @@ if __name__ == "__main__":
         masks_and_surgery()
     if "flops" in which:
         flops_golden()
+    if "gsrl" in which:
+        gsrl_golden()

@@ -225,3 +225,25 @@ def test_ohem_threshold_and_loss_vs_oracle(cuda, case):
     else:
         assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
         assert rel_err(zg.grad, zr.grad) < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_gsrl_loss_vs_reference_golden(cuda, tag):
+    """CriterionGsrlDSN through the fused HIP kernels vs the reference's output (golden)."""
+    import os
+    import numpy as np
+    from dcfp_amd.loss.criterion import build_criterions
+
+    class DS:
+        ignore_label = 255; num_classes = 19; class_weights = None
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gsrl.npz"))
+    H, W, align = [int(v) for v in g[f"meta:{tag}"]]
+    crit = build_criterions("gsrl", DS(), {"ds_weight": 0.4})
+    z0 = torch.from_numpy(g[f"z0:{tag}"]).to(cuda).requires_grad_(True)
+    z1 = torch.from_numpy(g[f"z1:{tag}"]).to(cuda).requires_grad_(True)
+    labels = {"ori": torch.from_numpy(g[f"lab:{tag}"]).to(cuda), "weight": torch.from_numpy(g[f"wgt:{tag}"]).to(cuda)}
+    loss = crit.forward_lowres([z0, z1], labels, (H, W), bool(align))["loss"]
+    loss.backward()
+    assert abs(loss.item() - float(g[f"loss:{tag}"])) < 2e-6 * max(1.0, abs(float(g[f"loss:{tag}"])))
+    assert rel_err(z0.grad, torch.from_numpy(g[f"g0:{tag}"])) < 2e-5
+    assert rel_err(z1.grad, torch.from_numpy(g[f"g1:{tag}"])) < 2e-5

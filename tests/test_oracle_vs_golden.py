@@ -113,3 +113,18 @@ def test_oracle_masks_match_reference(gp):
             continue   # residual groups take the union of their members: checked in test_pruner_host
         ref = np.unpackbits(g["out:" + conv])[:mask.numel()]
         assert np.array_equal(mask.numpy().astype(np.uint8), ref), conv
+
+
+def test_gsrl_oracle_matches_reference():
+    import torch.nn.functional as F
+    from oracle import gsrl
+    g = _load("gsrl.npz")
+    for tag in ("a", "b"):
+        H, W, align = [int(v) for v in g[f"meta:{tag}"]]
+        z0 = torch.from_numpy(g[f"z0:{tag}"]).requires_grad_(True)
+        z1 = torch.from_numpy(g[f"z1:{tag}"]).requires_grad_(True)
+        p = [F.interpolate(z, size=(H, W), mode="bilinear", align_corners=bool(align)) for z in (z0, z1)]
+        loss = gsrl.gsrl_loss(p, torch.from_numpy(g[f"lab:{tag}"]), torch.from_numpy(g[f"wgt:{tag}"]))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g[f"loss:{tag}"])) < 1e-6
+        assert np.abs(z0.grad.numpy() - g[f"g0:{tag}"]).max() < 1e-7

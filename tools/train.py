@@ -113,6 +113,8 @@ def main(argv=None):
         per_rank = max(1, args.batch_size // engine.world_size)
         for it in range(args.start_iters, args.num_steps):
             images, labels = dataset.batch(per_rank, device)
+            if "gsrl" in args.loss_type:   # fine-tune stage: {'ori', 'weight'} labels (datasets/Base.py:73-89)
+                labels = {"ori": labels, "weight": 1.0 + (labels % 3 == 0).float()}
             optimizer.zero_grad()
             lr = adjust_learning_rate(optimizer, args.learning_rate, it, args.num_steps, args.power, args.warmup)
             loss = model(images, labels, deepsup=args.deepsup)
