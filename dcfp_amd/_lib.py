@@ -10,7 +10,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcfp_hip.so")
+LIB_PATH = os.environ.get("DCFP_LIB") or os.path.join(_HERE, "libdcfp_hip.so")   # DCFP_LIB: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
@@ -45,6 +45,7 @@ SIGNATURES = {
     "dcfp_conv2d_workspace_bytes": (_Z, [_D, _I]),
     "dcfp_conv2d_kernel_name": (_I, [_D, _I, C.c_char_p, _I]),
     "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P, _Z, _P]),
+    "dcfp_conv2d_fwd_fused_f32_nchw": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "dcfp_conv2d_dgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _I, _P, _Z, _P]),
     "dcfp_conv2d_wgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _P, _P, _Z, _P]),
     "dcfp_bn_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -72,6 +73,8 @@ SIGNATURES = {
     "dcfp_upsample_wce_workspace_bytes": (_Z, [_I, _I, _I]),
     "dcfp_upsample_wce_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "dcfp_upsample_wce_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "dcfp_upsample_argmax_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dcfp_confusion_matrix_i64": (_I, [_P, _P, _I, _L, _I, _P, _P]),
     "dcfp_eic_update_f32": (_I, [_P, _I, _F, _F, _P]),
     "dcfp_sgd_momentum_f32": (_I, [_P, _I, _L, _F, _F, _I, _P]),
 }

@@ -327,7 +327,9 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd);
 int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
                     const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
-                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                    const float* scale = nullptr, const float* shift = nullptr,
+                    const float* residual = nullptr, int relu = 0);
 
 // DCFP_IGEMM_V1=1 keeps the first-generation kernel (A/B comparisons in one process).
 static bool use_v1() {
@@ -410,4 +412,21 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     p.wgt_bytes = d->Cout * d->Cin * T * 4;
     p.vec_store = (p.P % 4 == 0) && dcfp_aligned16(dx);
     return T == 1 ? launch_taps<1>(p, dcfp_s(stream)) : launch_taps<9>(p, dcfp_s(stream));
+}
+
+// Inference: conv + folded eval-mode BatchNorm (+residual) (+ReLU) in the conv epilogue.
+extern "C" int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
+                                              const float* scale, const float* shift,
+                                              const float* residual, int relu, float* y,
+                                              void* workspace, size_t workspace_bytes,
+                                              dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y || !scale || !shift) return DCFP_E_BADDESC;
+    if (use_v1()) return DCFP_E_UNSUPPORTED;
+    const int T = d->KH * d->KW;
+    return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
+                           (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,
+                           d->Hout, d->Wout, d->stride, 1, -d->pad, d->dil, 0, workspace, workspace_bytes,
+                           dcfp_s(stream), scale, shift, residual, relu ? 1 : 0);
 }

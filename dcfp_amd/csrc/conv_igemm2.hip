@@ -22,13 +22,17 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
+constexpr int BK = 16;      // default K-step depth
 constexpr unsigned kOob = 0x80000000u;
 
 struct Igemm2Params {
     const float* in;
     const float* wp;    // permuted weights [T][CkP][Mpad]
     const float* bias;
+    const float* scale;     // inference epilogue: y = act(acc*scale[m] + shift[m] (+ residual))
+    const float* shift;
+    const float* residual;  // same layout as out
+    int relu;
     float* out;
     long long in_nstride, out_nstride;
     int N, M, Mpad, Ck, CkP;
@@ -85,8 +89,10 @@ struct Frag<1> {
 };
 
 // ACC: dx += result (gradient fan-in of a residual branch); only the epilogue differs.
-template <int TAPS, int TM, int TN, int WM, int WN, bool SD, bool ACC>
+template <int TAPS, int TM, int TN, int WM, int WN, bool SD, bool ACC, int KB = 16>
 __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params p) {
+    constexpr int BK = KB;     // shadows the file-level default: K-step depth of this instance
+    constexpr int NPART = BK / 4;   // staging is issued in NPART parts over the first NPART MFMA slots
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     // A: thread -> (4 consecutive m, rows ay + AROWS*j)
     constexpr int AX = BM / 4;                       // threads across a row
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
         if (PART == 0 && c0 == 0) set_tap(t);
         static_for<0, APASS>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if constexpr ((j & 3) == PART) {
+            if constexpr ((j % NPART) == PART) {
                 if (a_on)
                     areg[j] = *reinterpret_cast<const f32x4*>(
                         a_src + (long long)(t * p.CkP + c0 + ay + AROWS * j) * p.Mpad);
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
         });
         static_for<0, RPT>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
-            if constexpr ((q & 3) == PART) {
+            if constexpr ((q % NPART) == PART) {
                 int c = c0 + ty + TY * q;
                 c = c < p.Ck ? c : p.Ck - 1;        // rows past Ck meet zero rows of Wp
                 const unsigned coff = (unsigned)(c * HiWi) * 4u;
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    static_for<0, 4>([&](auto part_) { load_part(0, part_); });
+    static_for<0, NPART>([&](auto part_) { load_part(0, part_); });
     store_a(0);
     store_b(0);
     __syncthreads();
@@ -252,9 +258,9 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
                 Frag<TN>::ld(b + (2 * kk + 2) * BN, bf[fc ^ 1]);
             }
             if (more) {
-                if constexpr (kk < 4) load_part(kt + 1, std::integral_constant<int, kk>{});
-                if constexpr (kk == 6) store_a(cur ^ 1);
-                if constexpr (kk == 7) store_b(cur ^ 1);
+                if constexpr (kk < NPART) load_part(kt + 1, std::integral_constant<int, kk>{});
+                if constexpr (kk == BK / 2 - 2) store_a(cur ^ 1);
+                if constexpr (kk == BK / 2 - 1) store_b(cur ^ 1);
             }
             static_for<0, TM>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
@@ -263,6 +269,13 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fc][i], bf[fc][j], acc[i][j], 0, 0, 0);
                 });
             });
+#ifdef DCFP_SGB
+            // ask the scheduler for MFMA, few others, MFMA, ... instead of [all staging][16 MFMA]
+            static_for<0, TM * TN>([&](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x096, DCFP_SGB, 0);
+            });
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         __syncthreads();
@@ -311,6 +324,26 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
             }
             if (ACC) { v[0] += old[r].x; v[1] += old[r].y; v[2] += old[r].z; v[3] += old[r].w; }
             float* dst = o_img + (long long)m * p.P + pix;
+            if (p.scale) {   // folded eval-mode BatchNorm (+residual) (+ReLU)
+                const float sc = p.scale[m], sf = p.shift[m];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = fmaf(v[j], sc, sf);
+                if (p.residual) {
+                    const float* rsrc = p.residual + (dst - p.out);
+                    if (vec) {
+                        const float4 rv = *reinterpret_cast<const float4*>(rsrc);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            if (pix + j < p.P) v[j] += rsrc[j];
+                    }
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
             if (vec) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -324,14 +357,15 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params
     }
 }
 
-template <int TAPS, int TM, int TN, int WM, int WN, bool SD = false, bool ACC = false>
+template <int TAPS, int TM, int TN, int WM, int WN, bool SD = false, bool ACC = false, int KB = 16>
 int launch_cfg(Igemm2Params& p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
+    constexpr int BK = KB;
     const long long groups = ((long long)p.tiles_n_total + 7) / 8;
     const long long blocks = groups * 8 * p.tiles_m;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
-    auto kern = igemm2_kernel<TAPS, TM, TN, WM, WN, SD, ACC>;
+    auto kern = igemm2_kernel<TAPS, TM, TN, WM, WN, SD, ACC, KB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -340,6 +374,13 @@ int launch_cfg(Igemm2Params& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, stream, p);
     DCFP_RETURN_LAUNCH();
 }
+
+// DCFP_IGEMM_BK32=1: 32-deep K-steps for the 256x256 tile (half the barriers; 128 KB of LDS)
+static bool deep_k() {
+    static const bool v = getenv("DCFP_IGEMM_BK32") != nullptr;
+    return v;
+}
+static int ck_pad() { return deep_k() ? 32 : BK; }
 
 struct TileCfg { int bm, bn, id; };
 // 0: 32x512  1: 64x512  2: 128x256  3: 128x128  4: 256x256  5: 128x256 strided-dgrad
@@ -353,6 +394,7 @@ TileCfg pick_cfg(int M, long long px, int sd) {
     if (blocks(128, 256) >= 192) return {128, 256, 2};
     return {128, 128, 3};
 }
+
 
 template <int TAPS>
 int launch_taps(Igemm2Params& p, int cfg, hipStream_t stream) {
@@ -369,7 +411,9 @@ int launch_taps(Igemm2Params& p, int cfg, hipStream_t stream) {
         case 1: return launch_cfg<TAPS, 2, 4, 1, 4>(p, stream);
         case 2: return launch_cfg<TAPS, 2, 4, 2, 2>(p, stream);
         case 3: return launch_cfg<TAPS, 2, 2, 2, 2>(p, stream);
-        case 4: return launch_cfg<TAPS, 4, 4, 2, 2>(p, stream);
+        case 4:
+            if (deep_k()) return launch_cfg<TAPS, 4, 4, 2, 2, false, false, 32>(p, stream);
+            return launch_cfg<TAPS, 4, 4, 2, 2>(p, stream);
         default: return launch_cfg<TAPS, 2, 4, 2, 2, true>(p, stream);
     }
 }
@@ -381,7 +425,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // ---- entry points used by conv_igemm.hip's C-ABI functions
 size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
     const TileCfg c = pick_cfg(M, px, sd);
-    return (size_t)T * round_up(Ck, BK) * round_up(M, c.bm) * sizeof(float);
+    return (size_t)T * round_up(Ck, ck_pad()) * round_up(M, c.bm) * sizeof(float);
 }
 
 const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
@@ -399,13 +443,15 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
 int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
                     const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
-                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                    const float* scale, const float* shift, const float* residual, int relu) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
     p.in = in; p.bias = bias; p.out = out;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
-    p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, BK); p.Mpad = round_up(M, c.bm);
+    p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
     p.tiles_per_img = (p.P + c.bn - 1) / c.bn;
     p.tiles_n_total = p.tiles_per_img * N;

@@ -453,6 +453,64 @@ upsample_wce_bwd_kernel(const float* __restrict__ logits, const long long* __res
     }
 }
 
+template <bool ALIGN>
+__global__ void __launch_bounds__(kThreads)
+upsample_argmax_kernel(const float* __restrict__ logits, int N, int C, int h, int w, int H, int W,
+                       float sh, float sw, int* __restrict__ pred) {
+    const long long total = (long long)N * H * W;
+    const long long plane = (long long)h * w;
+    for (long long pix = (long long)blockIdx.x * kThreads + threadIdx.x; pix < total;
+         pix += (long long)gridDim.x * kThreads) {
+        const int X = (int)(pix % W);
+        const long long t = pix / W;
+        const int Y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Lerp Lh = lerp_of<ALIGN>(Y, sh, h), Lw = lerp_of<ALIGN>(X, sw, w);
+        const int o00 = Lh.i0 * w + Lw.i0, o01 = Lh.i0 * w + Lw.i1;
+        const int o10 = Lh.i1 * w + Lw.i0, o11 = Lh.i1 * w + Lw.i1;
+        const float* base = logits + (long long)n * C * plane;
+        float best = -INFINITY;
+        int bi = 0;
+        for (int c = 0; c < C; ++c) {
+            const float* p = base + c * plane;
+            const float z = Lh.l0 * (Lw.l0 * p[o00] + Lw.l1 * p[o01]) +
+                            Lh.l1 * (Lw.l0 * p[o10] + Lw.l1 * p[o11]);
+            if (z > best) { best = z; bi = c; }     // first maximum wins, like torch.argmax / np.argmax
+        }
+        pred[pix] = bi;
+    }
+}
+
+// per-block LDS histogram (C*C <= 4096 bins), then one integer atomic per non-empty bin
+__global__ void __launch_bounds__(kThreads)
+confusion_kernel(const int* __restrict__ pred, const long long* __restrict__ gt, int ignore_index,
+                 long long n, int C, unsigned long long* __restrict__ conf) {
+    extern __shared__ unsigned int hist[];
+    const int bins = C * C;
+    for (int i = threadIdx.x; i < bins; i += kThreads) hist[i] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (long long)gridDim.x * kThreads) {
+        const long long g = gt[i];
+        const int p = pred[i];
+        if (g != ignore_index && g >= 0 && g < C && p >= 0 && p < C) atomicAdd(&hist[(int)g * C + p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += kThreads)
+        if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
+__global__ void __launch_bounds__(kThreads)
+confusion_global_kernel(const int* __restrict__ pred, const long long* __restrict__ gt, int ignore_index,
+                        long long n, int C, unsigned long long* __restrict__ conf) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (long long)gridDim.x * kThreads) {
+        const long long g = gt[i];
+        const int p = pred[i];
+        if (g != ignore_index && g >= 0 && g < C && p >= 0 && p < C) atomicAdd(&conf[g * C + p], 1ull);
+    }
+}
+
 inline unsigned stream_grid(long long total) {
     long long b = (total + kThreads - 1) / kThreads;
     if (b > 256 * 16) b = 256 * 16;
@@ -645,5 +703,36 @@ extern "C" int dcfp_upsample_wce_bwd_f32(const float* logits, const int64_t* lab
         hipLaunchKernelGGL(upsample_wce_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
                            dcfp_s(stream), logits, lab, pix_weight, ignore_index, N, C, h, w, H, W, sh, sw,
                            lse, grad_scale_per_image, dlogits);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_upsample_argmax_f32(const float* logits, int N, int C, int h, int w, int H, int W,
+                                        int align_corners, int32_t* pred, dcfp_stream_t stream) {
+    if (!logits || !pred || N <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
+    const long long total = (long long)N * H * W;
+    const float sh = host_scale(h, H, align_corners), sw = host_scale(w, W, align_corners);
+    if (align_corners)
+        hipLaunchKernelGGL(upsample_argmax_kernel<true>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, N, C, h, w, H, W, sh, sw, pred);
+    else
+        hipLaunchKernelGGL(upsample_argmax_kernel<false>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), logits, N, C, h, w, H, W, sh, sw, pred);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_confusion_matrix_i64(const int32_t* pred, const int64_t* gt, int ignore_index,
+                                         int64_t n_pixels, int C, int64_t* conf, dcfp_stream_t stream) {
+    if (!pred || !gt || !conf || n_pixels < 0 || C <= 0 || C > 1024) return DCFP_E_BADDESC;
+    if (n_pixels == 0) return DCFP_OK;
+    long long b = (n_pixels + kThreads - 1) / kThreads;
+    if (b > 1024) b = 1024;
+    if (C <= 64)
+        hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)b), dim3(kThreads), (size_t)C * C * sizeof(unsigned),
+                           dcfp_s(stream), pred, reinterpret_cast<const long long*>(gt), ignore_index,
+                           (long long)n_pixels, C, reinterpret_cast<unsigned long long*>(conf));
+    else   // ADE (150) / COCO-Stuff (171): the histogram does not fit LDS, count in global memory
+        hipLaunchKernelGGL(confusion_global_kernel, dim3((unsigned)b), dim3(kThreads), 0, dcfp_s(stream), pred,
+                           reinterpret_cast<const long long*>(gt), ignore_index, (long long)n_pixels, C,
+                           reinterpret_cast<unsigned long long*>(conf));
     DCFP_RETURN_LAUNCH();
 }

@@ -46,6 +46,31 @@ def bn_act(m, x, relu=False, residual=None):
     return ops.batch_norm_act(x, m.weight, m.bias, rm, rv, residual, relu, training, momentum, eps, sync)
 
 
+def _fold(bn):
+    """(scale, shift) of an eval-mode BatchNorm, cached until its tensors change."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+    cached = getattr(bn, "_dcfp_fold", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+        cached = (key, scale.contiguous(), shift.contiguous())
+        bn._dcfp_fold = cached
+    return cached[1], cached[2]
+
+
+def conv_bn_act(cm, bn, x, relu=False, residual=None):
+    """conv -> BatchNorm (+residual) (+ReLU).  Inference (BN in eval mode, no autograd): ONE kernel,
+    the BN folded into the conv epilogue; otherwise conv + the training BN kernels."""
+    if (not bn.training) and bn.running_mean is not None and not torch.is_grad_enabled() \
+            and cm.bias is None and cm.groups == 1 and cm.padding_mode == "zeros":
+        scale, shift = _fold(bn)
+        return ops.conv2d_fused_infer(x, cm.weight, scale, shift, cm.stride[0], cm.padding[0],
+                                      cm.dilation[0], residual, relu)
+    return bn_act(bn, conv(cm, x), relu=relu, residual=residual)
+
+
 def _plain_conv(m, k):
     ok = (m.groups == 1 and m.bias is None and m.kernel_size == (k, k) and m.padding_mode == "zeros"
           and not isinstance(m.padding, str))
@@ -80,7 +105,11 @@ def run_sequential(seq, x):
     i = 0
     while i < len(mods):
         m = mods[i]
-        if isinstance(m, nn.Conv2d):
+        if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], _BN_TYPES):
+            fuse = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            x = conv_bn_act(m, mods[i + 1], x, relu=fuse)
+            i += 2 if fuse else 1
+        elif isinstance(m, nn.Conv2d):
             x = conv(m, x)
         elif isinstance(m, _BN_TYPES):
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)

@@ -37,11 +37,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         if _exec.FUSE_BLOCKS and x.requires_grad:
             return _exec.bottleneck(self, x)   # one autograd node; residual grad fused into dgrad
-        out = _exec.bn_act(self.bn1, _exec.conv(self.conv1, x), relu=True)
-        out = _exec.bn_act(self.bn2, _exec.conv(self.conv2, out), relu=True)
-        out = _exec.conv(self.conv3, out)
+        out = _exec.conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        out = _exec.conv_bn_act(self.conv2, self.bn2, out, relu=True)
         residual = x if self.downsample is None else _exec.run_sequential(self.downsample, x)
-        return _exec.bn_act(self.bn3, out, relu=True, residual=residual)
+        return _exec.conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=residual)
 
 
 class ResNet(nn.Module):
@@ -81,8 +80,9 @@ class ResNet(nn.Module):
 
     def forward(self, input):
         _exec.require_device(input)
-        x = _exec.run_sequential(self.conv1, input)
-        x = _exec.bn_act(self.bn1, x, relu=True)
+        stem = list(self.conv1.children())
+        x = _exec.run_sequential(nn.Sequential(*stem[:-1]), input)
+        x = _exec.conv_bn_act(stem[-1], self.bn1, x, relu=True)
         x = ops.maxpool3x3s2(x)
         outs = []
         for i in range(1, 5):

@@ -63,11 +63,15 @@ class Seg_Model(nn.Module):
         if self.deepsup:
             self.conv_deepsup = _deepsup_head(in_channels[0], num_classes)
 
-    def forward(self, input, labels=None, deepsup=False):
+    def lowres_logits(self, input, deepsup=False):
+        """Logits of the head(s) at 1/os resolution (before the bilinear upsample)."""
         _exec.require_device(input)
         x_deepsup, x = self.backbone(input)
         x = self.aspp(x)
         lowres = [_exec.run_sequential(self.last_conv, x)]
         if self.deepsup and deepsup:
             lowres.append(_exec.run_sequential(self.conv_deepsup, x_deepsup))
-        return finish(self, input, lowres, labels)
+        return lowres
+
+    def forward(self, input, labels=None, deepsup=False):
+        return finish(self, input, self.lowres_logits(input, deepsup), labels)

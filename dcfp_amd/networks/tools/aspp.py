@@ -21,7 +21,7 @@ class _ASPPModule(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return _exec.bn_act(self.bn, _exec.conv(self.atrous_conv, x), relu=True)
+        return _exec.conv_bn_act(self.atrous_conv, self.bn, x, relu=True)
 
 
 class ASPP(nn.Module):
@@ -51,5 +51,5 @@ class ASPP(nn.Module):
         x5 = ops.broadcast_to_hw(x5, x4.shape[2], x4.shape[3])
         x = torch.cat((x1, x2, x3, x4, x5), dim=1)
         if self.outplanes is not None:
-            x = _exec.bn_act(self.bn1, _exec.conv(self.conv1, x), relu=True)
+            x = _exec.conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return x

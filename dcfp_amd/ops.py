@@ -708,3 +708,47 @@ class UpsampleWCEFn(torch.autograd.Function):
 def upsample_weighted_ce(logits, labels, pix_weight, size, align_corners, ignore_index=255):
     return UpsampleWCEFn.apply(logits, labels, pix_weight, int(size[0]), int(size[1]), align_corners,
                                ignore_index)
+
+
+# ------------------------------------------------------------------ inference / evaluation
+def conv2d_fused_infer(x, w, scale, shift, stride=1, pad=0, dil=1, residual=None, relu=False):
+    """y = act(conv(x,w)*scale[co] + shift[co] (+ residual)): conv with an eval-mode BatchNorm
+    folded into its epilogue (no autograd: inference only)."""
+    _require(x, "x"); _require(w, "weight")
+    x = x.contiguous(); w = w.contiguous()
+    d = _desc(x.shape, w.shape, stride, pad, dil)
+    y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = residual.contiguous()
+        if tuple(residual.shape) != tuple(y.shape):
+            raise RuntimeError("conv2d_fused_infer: residual shape mismatch")
+    L = _lib.lib()
+    ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), x.device)
+    check(L.dcfp_conv2d_fwd_fused_f32_nchw(C.byref(d), _p(x), _p(w), _p(scale.contiguous()),
+                                           _p(shift.contiguous()), _p(residual), int(bool(relu)), _p(y),
+                                           _p(ws), ws.numel(), _stream()), "conv2d_fwd_fused")
+    return y
+
+
+def upsample_argmax(logits, size, align_corners):
+    """argmax over classes of F.interpolate(logits, size) per pixel -> int32 [N,H,W]."""
+    _require(logits, "logits")
+    logits = logits.contiguous()
+    N, Cc, h, w = logits.shape
+    H, W = int(size[0]), int(size[1])
+    pred = torch.empty((N, H, W), dtype=torch.int32, device=logits.device)
+    check(_lib.lib().dcfp_upsample_argmax_f32(_p(logits), N, Cc, h, w, H, W, int(bool(align_corners)),
+                                              _p(pred), _stream()), "upsample_argmax")
+    return pred
+
+
+def confusion_matrix(pred, gt, num_classes, ignore_index=255, out=None):
+    """conf[gt, pred] += 1 over pixels with gt != ignore (evaluate.py:229-247); int64 [C,C]."""
+    if pred.dtype != torch.int32 or gt.dtype != torch.int64 or not pred.is_cuda or not gt.is_cuda:
+        raise RuntimeError("confusion_matrix: pred int32 / gt int64 CUDA tensors expected")
+    pred = pred.contiguous(); gt = gt.contiguous()
+    if out is None:
+        out = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=pred.device)
+    check(_lib.lib().dcfp_confusion_matrix_i64(_p(pred), _p(gt), int(ignore_index), pred.numel(),
+                                               int(num_classes), _p(out), _stream()), "confusion_matrix")
+    return out

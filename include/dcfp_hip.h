@@ -69,6 +69,13 @@ int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float*
                              const float* bias, float* y, int64_t y_nstride,
                              void* workspace, size_t workspace_bytes,
                              dcfp_stream_t stream);
+/* Inference path (evaluate.py:186-196 predict_whole): conv with the eval-mode BatchNorm folded
+ * into the epilogue: y = act( conv(x,w)[co]*scale[co] + shift[co] (+ residual) ), act = ReLU if relu
+ * (scale = gamma*rsqrt(running_var+eps), shift = beta - running_mean*scale).  Dense y / residual. */
+int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
+                                   const float* scale, const float* shift, const float* residual,
+                                   int relu, float* y, void* workspace, size_t workspace_bytes,
+                                   dcfp_stream_t stream);
 /* dx = conv_transpose(dy, w); accumulate != 0 => dx += (fan-out gradients).
  * dy_nstride: batch stride of dy in elements (0 => dense). */
 int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
@@ -206,6 +213,15 @@ int dcfp_upsample_wce_bwd_f32(const float* logits, const int64_t* labels, const 
                               int ignore_index, int N, int C, int h, int w, int H, int W,
                               int align_corners, const float* lse,
                               const float* grad_scale_per_image, float* dlogits,
+                              dcfp_stream_t stream);
+
+/* Evaluation (evaluate.py:229-247,340-372): pred = argmax_c F.interpolate(logits)[c] per pixel
+ * (never materialising the full-resolution logits) and the class confusion matrix
+ * conf[gt*C + pred] += 1 over pixels with gt != ignore_index (int64, integer atomics: exact). */
+int dcfp_upsample_argmax_f32(const float* logits, int N, int C, int h, int w, int H, int W,
+                             int align_corners, int32_t* pred, dcfp_stream_t stream);
+int dcfp_confusion_matrix_i64(const int32_t* pred, const int64_t* gt, int ignore_index,
+                              int64_t n_pixels, int C, int64_t* conf /* [C*C], accumulated */,
                               dcfp_stream_t stream);
 
 /* ------------------------------------------------------------- EIC score

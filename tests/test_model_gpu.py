@@ -247,3 +247,35 @@ def test_train_score_prune_finetune_pipeline(cuda, tmp_path):
                          "--snapshot-dir", d3])
     sd = torch.load(d3 + "/CS_scenes_2.pth")
     assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+
+
+def test_inference_path_vs_oracle(cuda):
+    """Eval-mode forward (BN folded into the conv epilogues), fused upsample+argmax and the
+    device confusion matrix / mIoU against the CPU oracle (evaluate.py:186-247,374-380)."""
+    from dcfp_amd import evaluate as ev
+    from oracle import evalmetrics
+    m = build("deeplabv3", "resnet50", True, cuda)
+    m.criterion = None
+    m.eval()
+    x = fill.closed_form_input(2, 97, 129)
+    lab = fill.closed_form_labels(2, 97, 129)
+    cfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
+    osd = omodel.clone_state({k: v.cpu() for k, v in m.state_dict().items()}, requires_grad=False)
+    with torch.no_grad():
+        outs, _, _ = omodel.seg_forward(osd, x, cfg, None, training=False)
+    logits = ev.predict_whole(m, x.to(cuda))
+    # eval-mode logits with untrained running statistics are O(100): compare relative to their scale
+    assert (logits.cpu() - outs[0]).abs().max().item() < 1e-4 * outs[0].abs().max().item()
+    ms = ev.predict_multiscale(m, x.to(cuda), [0.75, 1.0], 19, True, True)
+    assert tuple(ms.shape) == (2, 19, 97, 129) and torch.isfinite(ms).all()
+    pred = ev.predict_labels(m, x.to(cuda)).cpu().numpy()
+    ref_pred = outs[0].argmax(1).numpy()
+    top2 = outs[0].topk(2, dim=1).values
+    decisive = ((top2[:, 0] - top2[:, 1]) > 1e-4 * outs[0].abs().max()).numpy()      # ignore argmax ties inside fp32 noise
+    assert (pred[decisive] == ref_pred[decisive]).all() and decisive.mean() > 0.99
+    cm = ev.get_confusion_matrix(lab.to(cuda), torch.from_numpy(pred).to(cuda), 19).cpu().numpy()
+    keep = lab.numpy() != 255
+    ref_cm = evalmetrics.confusion_matrix(lab.numpy()[keep], pred[keep], 19)
+    assert np.array_equal(cm, ref_cm.astype(np.int64))
+    miou, _ = ev.mean_iou(torch.from_numpy(cm))
+    assert abs(miou - evalmetrics.mean_iou(ref_cm)[0]) < 1e-12
