@@ -263,9 +263,26 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad2_kernel(const WgradParams 
     float* As = smem;                     // [2][BM][BKP]
     float* Bs = smem + 2 * BM * BKP;      // [2][BN][BKP]
 
+    // block -> (split, tile): the tiles of one K-split share blockIdx % 8 (= one XCD under the
+    // round-robin dispatch), so the dy / x pixels of that split are fetched into ONE L2 and the
+    // other tiles of the split hit there; splits are dealt to the 8 XCD groups in turn
     const int tiles = p.tiles_m * p.tiles_n;
-    const int split = blockIdx.x / tiles;
-    const int tile = blockIdx.x - split * tiles;
+    int split, tile;
+    {
+        const int full = (p.splits / 8) * 8;              // splits covered by whole groups of 8
+        const int gsz = 8 * tiles;
+        const int b = blockIdx.x;
+        if (b < (full / 8) * gsz) {
+            const int g = b / gsz, r = b - g * gsz;
+            tile = r >> 3;
+            split = g * 8 + (r & 7);
+        } else {                                         // tail: fewer than 8 splits left
+            const int r = b - (full / 8) * gsz;
+            const int rem = p.splits - full;
+            tile = r / rem;
+            split = full + (r - tile * rem);
+        }
+    }
     const int mt = tile / p.tiles_n, ntile = tile - mt * p.tiles_n;
     const int m0 = mt * BM, n0 = ntile * BN;
     const int kbeg = split * p.kchunk;
