@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--size", default="1024,2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample", default="2,256,512", help="n,h,w of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="2,512,1024", help="n,h,w of the CPU baseline sample")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in SyncBN+DDP and run the collectives even at world size 1 (rehearsal)")
     args, _ = ap.parse_known_args()
