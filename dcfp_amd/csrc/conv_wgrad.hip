@@ -16,7 +16,14 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
+
+// EXPERIMENTAL opt-in: DCFP_CONV_MATH=bf16x3 routes qualifying wgrad shapes to conv_wgrad3.hip
+int dcfp_wgrad3_launch(const float* dy, long long dy_nstride, const float* x, long long x_nstride,
+                       float* out, int N, int M, int Cin, int T, int H, int W, int Ho, int Wo, int pad,
+                       int dil, int Kpix, int kchunk, int splits, int tiles_m, int tiles_n,
+                       hipStream_t stream);
 
 namespace {
 
@@ -638,6 +645,15 @@ int check_desc(const DcfpConvDesc* d) {
     return DCFP_OK;
 }
 
+// EXPERIMENTAL opt-in: DCFP_CONV_MATH=bf16x3 routes qualifying wgrad shapes to conv_wgrad3.hip
+static bool math_bf16x3() {
+    static const bool v = [] { const char* e = getenv("DCFP_CONV_MATH"); return e && !strcmp(e, "bf16x3"); }();
+    return v;
+}
+static bool wgrad3_ok(const DcfpConvDesc* d, int cfg) {
+    return math_bf16x3() && cfg == 0 && d->stride == 1 && (d->Wout % 4 == 0);
+}
+
 static bool wgrad_v1() {
     static const bool v = getenv("DCFP_WGRAD_V1") != nullptr;
     return v;
@@ -674,6 +690,7 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : "2,2,1,1";
+    if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
     return snprintf(buf, buf_len, "%s<%d,%s>", wgrad_v1() ? "wgrad_kernel" : "wgrad2_kernel", d->KH * d->KW, args);
 }
 
@@ -716,7 +733,12 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         const long long big = p.dy_nstride > p.x_nstride ? p.dy_nstride : p.x_nstride;
         if (span * big * 4 >= (1LL << 31)) return DCFP_E_UNSUPPORTED;
     }
-    rc = T == 1 ? launch_taps<1>(p, pl, dcfp_s(stream)) : launch_taps<9>(p, pl, dcfp_s(stream));
+    if (wgrad3_ok(d, pl.cfg))
+        rc = dcfp_wgrad3_launch(dy, p.dy_nstride, x, p.x_nstride, p.out, d->N, d->Cout, d->Cin, T, d->H, d->W,
+                                d->Hout, d->Wout, d->pad, d->dil, p.Kpix, pl.kchunk, pl.splits, pl.tiles_m,
+                                pl.tiles_n, dcfp_s(stream));
+    else
+        rc = T == 1 ? launch_taps<1>(p, pl, dcfp_s(stream)) : launch_taps<9>(p, pl, dcfp_s(stream));
     if (rc) return rc;
     if (pl.splits > 1) {
         long long b = (wn + 255) / 256;
