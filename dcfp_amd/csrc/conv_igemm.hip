@@ -18,6 +18,7 @@
 // K-step).  With the 4x4 wave tile a K-step is 128 MFMAs (8192 cycles/SIMD) against ~40
 // staging instructions per lane, which is why plain predicated dword loads suffice.
 #include "common.h"
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -337,12 +338,36 @@ static bool use_v1() {
     return v;
 }
 
+// implemented in conv_igemm3.hip — EXPERIMENTAL opt-in (DCFP_CONV_MATH=bf16x3): 3-way bf16 split
+size_t dcfp_igemm3_workspace_bytes(int T, int M, int Ck);
+int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
+                    const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
+                    int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
+                    void* workspace, size_t workspace_bytes, hipStream_t stream);
+int dcfp_igemm2_cfg_id(int M, long long px, int sd);
+static bool math_bf16x3() {
+    static const bool v = [] { const char* e = getenv("DCFP_CONV_MATH"); return e && !strcmp(e, "bf16x3"); }();
+    return v;
+}
+// the shapes the split kernel takes: unit sampling strides and the 256 x 256 tile of the fp32 path
+static bool igemm3_ok(int M, long long px, int sn, int sd) {
+    return math_bf16x3() && !use_v1() && sn == 1 && sd == 1 && dcfp_igemm2_cfg_id(M, px, sd) == 4;
+}
+
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK || use_v1()) return 0;
     const int T = d->KH * d->KW;
-    if (pass == DCFP_CONV_FWD)
-        return dcfp_igemm2_workspace_bytes(T, d->Cout, d->Cin, (long long)d->N * d->Hout * d->Wout, 1);
-    return dcfp_igemm2_workspace_bytes(T, d->Cin, d->Cout, (long long)d->N * d->H * d->W, d->stride);
+    size_t b2, b3 = 0;
+    if (pass == DCFP_CONV_FWD) {
+        const long long px = (long long)d->N * d->Hout * d->Wout;
+        b2 = dcfp_igemm2_workspace_bytes(T, d->Cout, d->Cin, px, 1);
+        if (igemm3_ok(d->Cout, px, d->stride, 1)) b3 = dcfp_igemm3_workspace_bytes(T, d->Cout, d->Cin);
+    } else {
+        const long long px = (long long)d->N * d->H * d->W;
+        b2 = dcfp_igemm2_workspace_bytes(T, d->Cin, d->Cout, px, d->stride);
+        if (igemm3_ok(d->Cin, px, 1, d->stride)) b3 = dcfp_igemm3_workspace_bytes(T, d->Cin, d->Cout);
+    }
+    return b2 > b3 ? b2 : b3;
 }
 
 extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_len) {
@@ -354,6 +379,8 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     p.N = d->N;
     if (pass == DCFP_CONV_FWD) { p.M = d->Cout; p.P = d->Hout * d->Wout; p.sd = 1; }
     else { p.M = d->Cin; p.P = d->H * d->W; p.sd = d->stride; }
+    if (igemm3_ok(p.M, (long long)p.N * p.P, pass == DCFP_CONV_FWD ? d->stride : 1, p.sd))
+        return snprintf(buf, buf_len, "igemm3_kernel<%d>", d->KH * d->KW);
     if (!use_v1())
         return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW,
                         dcfp_igemm2_cfg_args(p.M, (long long)p.N * p.P, p.sd));
@@ -368,6 +395,11 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     if (rc) return rc;
     if (!x || !w || !y) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))
+        return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
+                               y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
+                               d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, -d->pad, d->dil, 0,
+                               workspace, workspace_bytes, dcfp_s(stream));
     if (!use_v1())
         return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                                y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
@@ -395,6 +427,11 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (rc) return rc;
     if (!dy || !w || !dx) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (igemm3_ok(d->Cin, (long long)d->N * d->H * d->W, 1, d->stride))
+        return dcfp_igemm3_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
+                               T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
+                               d->Cout, T, d->Hout, d->Wout, d->H, d->W, d->pad, -d->dil,
+                               accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream));
     if (!use_v1())
         return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
                                T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,

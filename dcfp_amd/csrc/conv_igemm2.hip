@@ -441,6 +441,8 @@ size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
     return (size_t)T * round_up(Ck, ck_pad()) * round_up(M, c.bm) * sizeof(float);
 }
 
+int dcfp_igemm2_cfg_id(int M, long long px, int sd) { return pick_cfg(M, px, sd).id; }
+
 const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
     switch (pick_cfg(M, px, sd).id) {
         case 0: return "1,4,1,4,0";

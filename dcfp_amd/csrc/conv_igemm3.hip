@@ -1,0 +1,424 @@
+// conv_igemm3.hip — EXPERIMENTAL (opt-in: DCFP_CONV_MATH=bf16x3): implicit-GEMM conv forward /
+// data gradient with fp32 operands split three ways into bf16 (x = hi + mid + lo, exact for
+// normal numbers) and each product formed from the six leading bf16 x bf16 terms on the bf16
+// matrix cores with fp32 accumulation (see conv_wgrad3.hip for the arithmetic and its measured
+// error).  The default path stays the exact-fp32 MFMA kernel of conv_igemm2.hip; this one covers
+// the shapes that dominate the DeepLabv3-R101 step: stride 1, >= 192 output channels, 256 x 256
+// block tile.
+//
+// Operands of  Y[m][pix] = sum_{tap,c} W[m][c][tap] * X[c][pix + shift(tap)] :
+//  * A (weights) is split ONCE per call by permute_split_weights_kernel into
+//    Wp3[tap][c/16][plane][m][16 c] bf16, i.e. already in MFMA-fragment order (a lane's 8
+//    consecutive k are 16 contiguous bytes): the K loop copies 16-byte chunks global -> LDS
+//    ([m][16 k], pitch 24) with no arithmetic at all.
+//  * B (activations, NCHW: pixel-contiguous, k = channel strided) is loaded as pixel quads like
+//    the fp32 kernel, split in registers and stored AS LOADED into an LDS image [k][pixel]
+//    (pitch 288 bf16 = 16 banks mod 64).  The k-contiguous fragment the MFMA wants is produced by
+//    gfx950's transposing LDS read (ds_read_b64_tr_b16): two reads per plane and column tile,
+//    conflict-free on this pitch.
+// One K-step (16 channels of one tap) is 96 MFMAs x 32 cycles per wave; the staging work of the
+// next tile is cut into <= 5-instruction stages pinned behind individual MFMAs.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+constexpr int BM = 256, BN = 256;
+constexpr int APITCH = 24;                 // bf16 per A row (16 k + 8 pad)
+constexpr int BPITCH = 288;                // bf16 per B k-row (256 pixels + 32 pad)
+constexpr int APLANE = BM * APITCH;        // elements
+constexpr int BPLANE = BK * BPITCH;
+constexpr int ABUF = 3 * APLANE, BBUF = 3 * BPLANE;
+constexpr unsigned kOob = 0x80000000u;
+constexpr unsigned kMaxRecords = 0x7ffffffcu;
+
+struct Igemm3Params {
+    const float* in;
+    const __bf16* wp3;   // [T][CkP/16][3][Mpad][16]
+    const float* bias;
+    float* out;
+    long long in_nstride, out_nstride;
+    int N, M, Mpad, Ck, CkP;
+    int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
+    int off0, offstep;
+    int accumulate;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 t;
+    t[0] = (__bf16)a; t[1] = (__bf16)b;        // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, t);
+}
+// One step of the exact split of a pair: emit the bf16 pair nearest (a, b), leave the remainders.
+__device__ __forceinline__ unsigned peel(float& a, float& b) {
+    const unsigned h = pack_bf16(a, b);
+    a -= __builtin_bit_cast(float, h << 16);
+    b -= __builtin_bit_cast(float, h & 0xffff0000u);
+    return h;
+}
+// Split of one staged quad v[4] into packed planes pk = {hi01, hi23, mid01, mid23, lo01, lo23} in
+// five stages of <= 5 VALU instructions.  The empty asm pins each stage's results where they are
+// computed (IR-level sinking would otherwise move the arithmetic across the scheduling barriers).
+template <int K>
+__device__ __forceinline__ void split_stage(float (&v)[4], unsigned (&pk)[6]) {
+    if constexpr (K == 0) { pk[0] = peel(v[0], v[1]); asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(pk[0])); }
+    if constexpr (K == 1) { pk[1] = peel(v[2], v[3]); asm volatile("" : "+v"(v[2]), "+v"(v[3]), "+v"(pk[1])); }
+    if constexpr (K == 2) { pk[2] = peel(v[0], v[1]); asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(pk[2])); }
+    if constexpr (K == 3) { pk[3] = peel(v[2], v[3]); asm volatile("" : "+v"(v[2]), "+v"(v[3]), "+v"(pk[3])); }
+    if constexpr (K == 4) {
+        pk[4] = pack_bf16(v[0], v[1]); pk[5] = pack_bf16(v[2], v[3]);
+        asm volatile("" : "+v"(pk[4]), "+v"(pk[5]));
+    }
+}
+
+// Wp3[t][cb][plane][m][kk] <- split(W[m*sAm + (16 cb + kk)*sAc + t])   (zero for c >= Ck or m >= M)
+__global__ void __launch_bounds__(256)
+permute_split_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wp3, int T, int Ck, int CkP,
+                             int M, int Mpad, int sAm, int sAc) {
+    const long long total = (long long)T * CkP * Mpad;
+    const int ncb = CkP / 16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i & 15);
+        const long long r0 = i >> 4;
+        const int m = (int)(r0 % Mpad);
+        const long long r1 = r0 / Mpad;
+        const int cb = (int)(r1 % ncb);
+        const int t = (int)(r1 / ncb);
+        const int c = cb * 16 + kk;
+        float v = 0.f;
+        if (m < M && c < Ck) v = w[(long long)m * sAm + (long long)c * sAc + t];
+        const __bf16 h = (__bf16)v;
+        const float q1 = v - (float)h;
+        const __bf16 mi = (__bf16)q1;
+        const float q2 = q1 - (float)mi;
+        const long long plane = (long long)Mpad * 16;
+        __bf16* o = wp3 + ((long long)(t * ncb + cb) * 3) * plane + (long long)m * 16 + kk;
+        o[0] = h; o[plane] = mi; o[2 * plane] = (__bf16)q2;
+    }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+// the 8 consecutive k of one MFMA B fragment = two transposed 4-k blocks
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16* lo, const __bf16* hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)hi);
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TAPS>
+__global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_i3[];
+    __bf16* As = smem_i3;                // [2][3][BM][APITCH]
+    __bf16* Bs = smem_i3 + 2 * ABUF;     // [2][3][BK][BPITCH]
+
+    const int group = 8 * p.tiles_m;
+    const int g = blockIdx.x / group, local = blockIdx.x - g * group;
+    const int nt = g * 8 + (local & 7);
+    const int mt = local >> 3;
+    if (nt >= p.tiles_n_total) return;
+    const int img = nt / p.tiles_per_img;
+    const int p0 = (nt - img * p.tiles_per_img) * BN;
+    const int m0 = mt * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- A loader: six 16-byte chunks per thread and K-step; chunk h -> plane h>>1,
+    //      row (tid>>1) + 128*(h&1), k-half tid&1
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(p.wp3), 0, kMaxRecords, 0x00020000);
+    const unsigned a_voff = (unsigned)(((m0 + (tid >> 1)) * 16 + (tid & 1) * 8) * 2);
+    const unsigned a_plane_bytes = (unsigned)p.Mpad * 32u;
+    const int a_soff_lds = (tid >> 1) * APITCH + (tid & 1) * 8;
+
+    // ---- B loader: thread -> (4 consecutive pixels 4*tx.., channels ty + 4q)
+    const int tx = tid & 63, ty = tid >> 6;
+    int bh[4], bw[4];
+    bool pv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int pp = p0 + 4 * tx + e;
+        pv[e] = pp < p.P;
+        const int oh = pp / p.Wo;
+        bh[e] = oh;
+        bw[e] = pp - oh * p.Wo;
+    }
+    const int HiWi = p.Hi * p.Wi;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in + (long long)img * p.in_nstride), 0, p.Ck * HiWi * 4, 0x00020000);
+
+    const int kpt = p.CkP / BK;          // K-steps per tap
+    const int nk = TAPS * kpt;
+
+    unsigned boff[4];            // per-pixel byte offsets of the loader's current tap (kOob = padding)
+    bool bvec = false;           // the 4 pixels are one contiguous in-image run (or all padding)
+    int ld_t = 0, ld_cb = 0;     // (tap, channel block) of the tile the loader fetches next
+    unsigned a_step = 0;         // byte offset of that tile's first plane in Wp3
+    f32x4 areg[6];
+    float breg[4][4];
+
+    auto set_tap = [&](int t) {
+        const int kh = (TAPS == 9) ? t / 3 : 0;
+        const int kw = (TAPS == 9) ? t - kh * 3 : 0;
+        const int offh = p.off0 + kh * p.offstep;
+        const int offw = p.off0 + kw * p.offstep;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int hh = bh[e] + offh, ww = bw[e] + offw;
+            const bool ok = pv[e] && hh >= 0 && ww >= 0 && hh < p.Hi && ww < p.Wi;
+            boff[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+        }
+        const bool none = boff[0] == kOob && boff[1] == kOob && boff[2] == kOob && boff[3] == kOob;
+        const bool run = boff[0] != kOob && boff[1] == boff[0] + 4u && boff[2] == boff[0] + 8u &&
+                         boff[3] == boff[0] + 12u;
+        bvec = none || run;
+    };
+    // step the loader to the next tile in tap-major K order; past the last tile B fetches nothing
+    // (out-of-range offsets) and A re-reads the last tile
+    auto advance = [&]() {
+        if (++ld_cb == kpt) {
+            ld_cb = 0;
+            ++ld_t;
+            if (ld_t < TAPS) {
+                set_tap(ld_t);
+            } else {
+                boff[0] = boff[1] = boff[2] = boff[3] = kOob;
+                bvec = true;
+            }
+        }
+        const int t = ld_t < TAPS ? ld_t : TAPS - 1;
+        const int cb = ld_t < TAPS ? ld_cb : kpt - 1;
+        a_step = (unsigned)(t * kpt + cb) * 3u * a_plane_bytes;
+    };
+    auto load_a = [&](auto h_) {
+        constexpr int h = decltype(h_)::value;
+        const unsigned so = a_step + (unsigned)(h >> 1) * a_plane_bytes + (unsigned)(h & 1) * (128u * 32u);
+        areg[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, so, 0));
+    };
+    auto store_a = [&](int buf, auto h_) {
+        constexpr int h = decltype(h_)::value;
+        int so = a_soff_lds + buf * ABUF;
+        asm volatile("" : "+v"(so));
+        *reinterpret_cast<f32x4*>(As + so + (h >> 1) * APLANE + (h & 1) * 128 * APITCH) = areg[h];
+    };
+    auto load_b = [&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        int c = ld_cb * BK + ty + 4 * q;
+        c = c < p.Ck ? c : p.Ck - 1;        // rows past Ck meet zero rows of Wp3
+        const unsigned coff = (unsigned)(c * HiWi) * 4u;
+        if (bvec) {   // one (possibly unaligned) dwordx4; bit-cast the WHOLE vector (see conv_wgrad.hip)
+            const f32x4 v = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[0] + coff, 0, 0));
+            static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; breg[q][e] = v[e]; });
+        } else {
+            static_for<0, 4>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                breg[q][e] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, boff[e] + coff, 0, 0));
+            });
+        }
+    };
+    auto store_b = [&](int buf, auto q_, const unsigned (&pk)[6]) {
+        constexpr int q = decltype(q_)::value;
+        int so = ty * BPITCH + 4 * tx + buf * BBUF;
+        asm volatile("" : "+v"(so));
+        __bf16* d = Bs + so + 4 * q * BPITCH;
+        u32x2 h, m, l;
+        h[0] = pk[0]; h[1] = pk[1]; m[0] = pk[2]; m[1] = pk[3]; l[0] = pk[4]; l[1] = pk[5];
+        *reinterpret_cast<u32x2*>(d) = h;
+        *reinterpret_cast<u32x2*>(d + BPLANE) = m;
+        *reinterpret_cast<u32x2*>(d + 2 * BPLANE) = l;
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: tile 0 into LDS buffer 0, the loads of tile 1 in flight
+    set_tap(0);
+    static_for<0, 6>([&](auto h_) { load_a(h_); });
+    static_for<0, 4>([&](auto q_) { load_b(q_); });
+    static_for<0, 6>([&](auto h_) { store_a(0, h_); });
+    static_for<0, 4>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        unsigned pk[6];
+        split_stage<0>(breg[q], pk); split_stage<1>(breg[q], pk); split_stage<2>(breg[q], pk);
+        split_stage<3>(breg[q], pk); split_stage<4>(breg[q], pk);
+        store_b(0, q_, pk);
+    });
+    advance();
+    static_for<0, 6>([&](auto h_) { load_a(h_); });
+    static_for<0, 4>([&](auto q_) { load_b(q_); });
+    __syncthreads();
+
+    // fragment addresses (elements): A row-major 16-byte reads, B transposed 8-byte reads
+    const int a_frag = (wm * 128 + l31) * APITCH + 8 * lhi;
+    const int b_frag = (8 * (lane >> 5) + ((lane & 15) >> 2)) * BPITCH + wn * 128 + 16 * ((lane >> 4) & 1) +
+                       4 * (lane & 3);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        int ao = a_frag + cur * ABUF, bo = b_frag + cur * BBUF;
+        asm volatile("" : "+v"(ao), "+v"(bo));          // keep fragment addresses base + immediate
+        const __bf16* a = As + ao;
+        const __bf16* b = Bs + bo;
+        advance();                                      // loader -> tile kt+2
+        bf16x8 af[4][3];                                // [row tile][plane hi, mid, lo]
+        static_for<0, 4>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            static_for<0, 3>([&](auto pl_) {
+                constexpr int pl = decltype(pl_)::value;
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(a + pl * APLANE + i * 32 * APITCH);
+            });
+        });
+        bf16x8 bfr[2][3];
+        static_for<0, 3>([&](auto pl_) {
+            constexpr int pl = decltype(pl_)::value;
+            bfr[0][pl] = tr_read8(b + pl * BPLANE, b + pl * BPLANE + 4 * BPITCH);
+        });
+        static_for<0, 4>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            constexpr int c = j & 1;
+            unsigned pk[6];
+            // the staging stage pinned behind MFMA number k (0..23) of column tile j
+            auto stage = [&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                if constexpr (j < 3 && k < 3) {         // fragments of the next column tile
+                    bfr[c ^ 1][k] = tr_read8(b + k * BPLANE + (j + 1) * 32,
+                                             b + k * BPLANE + 4 * BPITCH + (j + 1) * 32);
+                }
+                if constexpr (k >= 4 && k <= 8) split_stage<k - 4>(breg[j], pk);
+                if constexpr (k == 9) store_b(cur ^ 1, j_, pk);
+                if constexpr (k == 10) load_b(j_);
+                if constexpr (k == 12) store_a(cur ^ 1, j_);
+                if constexpr (k == 13) load_a(j_);
+                constexpr int h2 = j < 2 ? j + 4 : 0;   // column tiles 0 and 1 also carry A chunks 4 and 5
+                if constexpr (j < 2 && k == 15) store_a(cur ^ 1, std::integral_constant<int, h2>{});
+                if constexpr (j < 2 && k == 16) load_a(std::integral_constant<int, h2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            static_for<0, 4>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                f32x16 cc = acc[i][j];
+                // small terms first
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[c][0], cc, 0, 0, 0);
+                stage(std::integral_constant<int, 6 * i + 0>{});
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[c][2], cc, 0, 0, 0);
+                stage(std::integral_constant<int, 6 * i + 1>{});
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[c][1], cc, 0, 0, 0);
+                stage(std::integral_constant<int, 6 * i + 2>{});
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[c][0], cc, 0, 0, 0);
+                stage(std::integral_constant<int, 6 * i + 3>{});
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[c][1], cc, 0, 0, 0);
+                stage(std::integral_constant<int, 6 * i + 4>{});
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[c][0], cc, 0, 0, 0);
+                stage(std::integral_constant<int, 6 * i + 5>{});
+                acc[i][j] = cc;
+            });
+        });
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (l31, lhi) holds, per (i, j), column pix_j of 16 rows
+    float* o_img = p.out + (long long)img * p.out_nstride;
+    int pix = p0 + wn * 128 + l31;
+    asm volatile("" : "+v"(pix));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int m = m0 + wm * 128 + i * 32 + row;
+            if (m >= p.M) continue;
+            const float bsv = p.bias ? p.bias[m] : 0.f;
+            float* dst = o_img + (long long)m * p.P + pix;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (pix + 32 * j < p.P) {
+                    float v = acc[i][j][r] + bsv;
+                    if (p.accumulate) v += dst[32 * j];
+                    dst[32 * j] = v;
+                }
+            }
+        }
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+// ---- entry points used by conv_igemm.hip when DCFP_CONV_MATH=bf16x3
+size_t dcfp_igemm3_workspace_bytes(int T, int M, int Ck) {
+    return (size_t)T * round_up(Ck, BK) * round_up(M, BM) * 3 * sizeof(__bf16);
+}
+
+// same argument meaning as dcfp_igemm2_run; stride-1 sampling only (sn == sd == 1)
+int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
+                    const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
+                    int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
+                    void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    Igemm3Params p;
+    p.in = in; p.bias = bias; p.out = out;
+    p.in_nstride = in_nstride; p.out_nstride = out_nstride;
+    p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, BK); p.Mpad = round_up(M, BM);
+    p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
+    p.tiles_per_img = (p.P + BN - 1) / BN;
+    p.tiles_n_total = p.tiles_per_img * N;
+    p.tiles_m = p.Mpad / BM;
+    p.off0 = off0; p.offstep = offstep;
+    p.accumulate = accumulate;
+    const size_t need = dcfp_igemm3_workspace_bytes(T, M, Ck);
+    if (!workspace || workspace_bytes < need || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
+    if ((long long)Ck * Hi * Wi * 4 > 0x7fffffffLL || need > 0x7fffffffULL) return DCFP_E_UNSUPPORTED;
+    __bf16* wp3 = static_cast<__bf16*>(workspace);
+    p.wp3 = wp3;
+    {
+        const long long total = (long long)T * p.CkP * p.Mpad;
+        long long b = (total + 255) / 256;
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL(permute_split_weights_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, wp3,
+                           T, Ck, p.CkP, M, p.Mpad, sAm, sAc);
+    }
+    const long long groups = ((long long)p.tiles_n_total + 7) / 8;
+    const long long blocks = groups * 8 * p.tiles_m;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * ABUF + 2 * BBUF) * sizeof(__bf16);
+    auto k1 = igemm3_kernel<1>;
+    auto k9 = igemm3_kernel<9>;
+    const void* kern = T == 1 ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k9);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    if (T == 1)
+        hipLaunchKernelGGL(igemm3_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL(igemm3_kernel<9>, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    DCFP_RETURN_LAUNCH();
+}

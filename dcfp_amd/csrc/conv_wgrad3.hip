@@ -10,8 +10,8 @@
 // Both wgrad operands are pixel(K)-contiguous in NCHW, which is exactly the bf16 MFMA fragment
 // shape (8 consecutive k per lane), so no transposition is needed: LDS holds three bf16 planes
 // per operand as [row][16 k] (pitch 24 bf16 = 48 B: conflict-free 16-byte reads).  A K-step is
-// only 96 MFMAs x 32 cycles, too short to hide a global load, so tiles are prefetched TWO
-// K-steps ahead through two register sets (K loop unrolled by 2).
+// only 96 MFMAs x 32 cycles, so each staged quad is re-loaded the moment it has been split and
+// stored: every global load gets one full K-step to land.
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,15 +47,40 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ void split4(const float (&v)[4], bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 h = (__bf16)v[e];
-        const float r1 = v[e] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[e] = h; mid[e] = m; lo[e] = (__bf16)r2;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 t;
+    t[0] = (__bf16)a; t[1] = (__bf16)b;        // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, t);
+}
+// One step of the exact split of a pair: emit the bf16 pair nearest (a, b), leave the remainders.
+__device__ __forceinline__ unsigned peel(float& a, float& b) {
+    const unsigned h = pack_bf16(a, b);
+    a -= __builtin_bit_cast(float, h << 16);
+    b -= __builtin_bit_cast(float, h & 0xffff0000u);
+    return h;
+}
+// The split of one staged quad v[4] into packed planes pk = {hi01, hi23, mid01, mid23, lo01, lo23},
+// cut into four stages of ~5 VALU instructions so that each hides behind one MFMA.
+template <int K>
+__device__ __forceinline__ void split_stage(float (&v)[4], unsigned (&pk)[6]) {
+    // the empty asm pins each stage's results where they are computed (IR-level sinking would
+    // otherwise move the arithmetic across the scheduling barriers to its first use)
+    if constexpr (K == 0) { pk[0] = peel(v[0], v[1]); asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(pk[0])); }
+    if constexpr (K == 1) { pk[1] = peel(v[2], v[3]); asm volatile("" : "+v"(v[2]), "+v"(v[3]), "+v"(pk[1])); }
+    if constexpr (K == 2) {
+        pk[2] = peel(v[0], v[1]); pk[4] = pack_bf16(v[0], v[1]);
+        asm volatile("" : "+v"(pk[2]), "+v"(pk[4]));
     }
+    if constexpr (K == 3) {
+        pk[3] = peel(v[2], v[3]); pk[5] = pack_bf16(v[2], v[3]);
+        asm volatile("" : "+v"(pk[3]), "+v"(pk[5]));
+    }
+}
+__device__ __forceinline__ void split4(float (&v)[4], unsigned (&pk)[6]) {
+    split_stage<0>(v, pk); split_stage<1>(v, pk); split_stage<2>(v, pk); split_stage<3>(v, pk);
 }
 
 // 256 x 256 tile, 2 x 2 waves, 4 x 4 MFMA tiles per wave; requires Wo % 4 == 0 and stride 1.
@@ -134,71 +159,63 @@ __global__ void __launch_bounds__(256) wgrad3_kernel(const Wgrad3Params p) {
         c_oh = pq / p.Wo;
         c_ow = pq - c_oh * p.Wo;
     }
-    float areg[1][PA][4], breg[1][PB][4];   // staging registers (next K-step)
+    float areg[2][PA][4], breg[2][PB][4];   // two staging sets: one quad per (operand, row group)
+    int q_a = 0, q_x = 0, q_ih = 0, q_iw = 0;
+    bool q_ok = false;
 
-    // issue the global loads of the K-step starting at pixel kbase into register set S
-    auto load_tile = [&](int kbase, auto s_) {
-        constexpr int S = decltype(s_)::value;
-        const int q0 = kbase + 4 * kx;
-        const bool q_ok = q0 < kend;
-        const int q_a = c_im * dyn + c_oh * p.Wo + c_ow;
-        const int q_x = c_im * xn + c_oh * p.W + c_ow;
-        const int q_ih = c_oh, q_iw = c_ow;
+    // pixel coordinates of this lane's quad in the K-step starting at kbase (advances the walker)
+    auto next_coords = [&](int kbase) {
+        q_ok = (kbase + 4 * kx) < kend;
+#if defined(W3_DBG_NOLOAD)
+        q_ok = false;
+#endif
+        q_a = c_im * dyn + c_oh * p.Wo + c_ow;
+        q_x = c_im * xn + c_oh * p.W + c_ow;
+        q_ih = c_oh; q_iw = c_ow;
         c_ow += BK;
         while (c_ow >= p.Wo) { c_ow -= p.Wo; ++c_oh; }
         while (c_oh >= p.Ho) { c_oh -= p.Ho; ++c_im; }
-        static_for<0, PA>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            const unsigned off = q_ok ? (unsigned)(q_a + a_off[j]) * 4u : kOob;
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
-            static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; areg[S][j][e] = v[e]; });
-        });
-        static_for<0, PB>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            const int hh = q_ih + b_dh[j], ww = q_iw + b_dw[j];
-            const bool rowok = q_ok && hh >= 0 && hh < p.H;
-            const unsigned base = (unsigned)(q_x + b_coff[j]) * 4u;
-            if (!rowok || (ww >= 0 && ww + 3 < p.W)) {
-                const f32x4 v = __builtin_bit_cast(
-                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, rowok ? base : kOob, 0, 0));
-                static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; breg[S][j][e] = v[e]; });
-            } else {
-                static_for<0, 4>([&](auto e_) {
-                    constexpr int e = decltype(e_)::value;
-                    const bool ok = (ww + e) >= 0 && (ww + e) < p.W;
-                    breg[S][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        b_rsrc, ok ? base + 4u * e : kOob, 0, 0));
-                });
-            }
-        });
     };
-    // split register set S into bf16 planes and store into LDS buffer `buf`
-    auto store_tile = [&](int buf, auto s_) {
+    auto load_a = [&](auto s_, auto j_) {
         constexpr int S = decltype(s_)::value;
-        // one opaque per-thread base per call: every LDS address below is base + immediate, instead
-        // of dozens of loop-invariant addresses hoisted out of the K loop (they spilled to scratch)
-        int so = rrow * PITCH + 4 * kx;
+        constexpr int j = decltype(j_)::value;
+        const unsigned off = q_ok ? (unsigned)(q_a + a_off[j]) * 4u : kOob;
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
+        static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; areg[S][j][e] = v[e]; });
+    };
+    auto load_b = [&](auto s_, auto j_) {
+        constexpr int S = decltype(s_)::value;
+        constexpr int j = decltype(j_)::value;
+        const int hh = q_ih + b_dh[j], ww = q_iw + b_dw[j];
+        const bool rowok = q_ok && hh >= 0 && hh < p.H;
+        const unsigned base = (unsigned)(q_x + b_coff[j]) * 4u;
+        if (!rowok || (ww >= 0 && ww + 3 < p.W)) {
+            const f32x4 v = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, rowok ? base : kOob, 0, 0));
+            static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; breg[S][j][e] = v[e]; });
+        } else {
+            static_for<0, 4>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                const bool ok = (ww + e) >= 0 && (ww + e) < p.W;
+                breg[S][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    b_rsrc, ok ? base + 4u * e : kOob, 0, 0));
+            });
+        }
+    };
+    // store the packed planes of one split quad into LDS buffer `buf`; every LDS address is one
+    // opaque per-thread base + immediate (loop-invariant addresses hoisted out of the K loop
+    // spilled to scratch)
+    auto store_planes = [&](__bf16* base, int buf, auto j_, const unsigned (&pk)[6]) {
+        constexpr int j = decltype(j_)::value;
+        int so = rrow * PITCH + 4 * kx + buf * (3 * PLANE);
         asm volatile("" : "+v"(so));
-        __bf16* a = As + buf * (3 * PLANE) + so;
-        __bf16* b = Bs + buf * (3 * PLANE) + so;
-        static_for<0, PA>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            bf16x4 h, m, l;
-            split4(areg[S][j], h, m, l);
-            constexpr int o = ROWS * j * PITCH;
-            *reinterpret_cast<bf16x4*>(a + o) = h;
-            *reinterpret_cast<bf16x4*>(a + PLANE + o) = m;
-            *reinterpret_cast<bf16x4*>(a + 2 * PLANE + o) = l;
-        });
-        static_for<0, PB>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            bf16x4 h, m, l;
-            split4(breg[S][j], h, m, l);
-            constexpr int o = ROWS * j * PITCH;
-            *reinterpret_cast<bf16x4*>(b + o) = h;
-            *reinterpret_cast<bf16x4*>(b + PLANE + o) = m;
-            *reinterpret_cast<bf16x4*>(b + 2 * PLANE + o) = l;
-        });
+        __bf16* d = base + so;
+        constexpr int o = ROWS * j * PITCH;
+        u32x2 h, m, l;
+        h[0] = pk[0]; h[1] = pk[1]; m[0] = pk[2]; m[1] = pk[3]; l[0] = pk[4]; l[1] = pk[5];
+        *reinterpret_cast<u32x2*>(d + o) = h;
+        *reinterpret_cast<u32x2*>(d + PLANE + o) = m;
+        *reinterpret_cast<u32x2*>(d + 2 * PLANE + o) = l;
     };
 
     f32x16 acc[4][4];
@@ -210,26 +227,40 @@ __global__ void __launch_bounds__(256) wgrad3_kernel(const Wgrad3Params p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    // prologue: tile 0 into LDS buffer 0; the loads of tiles 1 and 2 in flight (sets 1 and 0)
     using S0 = std::integral_constant<int, 0>;
-    if (nk > 0) {
-        load_tile(kbeg, S0{});
-        store_tile(0, S0{});
-    }
+    using S1 = std::integral_constant<int, 1>;
+    next_coords(kbeg);
+    static_for<0, 4>([&](auto j_) { load_a(S0{}, j_); load_b(S0{}, j_); });
+    next_coords(kbeg + BK);
+    static_for<0, 4>([&](auto j_) { load_a(S1{}, j_); load_b(S1{}, j_); });
+    static_for<0, 4>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        unsigned pk[6];
+        split4(areg[0][j], pk); store_planes(As, 0, j_, pk);
+        split4(breg[0][j], pk); store_planes(Bs, 0, j_, pk);
+    });
+    next_coords(kbeg + 2 * BK);
+    static_for<0, 4>([&](auto j_) { load_a(S0{}, j_); load_b(S0{}, j_); });
     __syncthreads();
 
     const int a_row = (wm * 128 + l31) * PITCH + 8 * lhi;
     const int b_row = (wn * 128 + l31) * PITCH + 8 * lhi;
 
-    // one K-step: MFMAs on LDS buffer kt&1; the loads of tile kt+1 are issued at its start and
-    // split + stored into the other buffer at its end
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K-step: 96 MFMAs on LDS buffer kt&1 in 8 slots.  Slot s splits + stores staged quad s of
+    // tile kt+1 (register set S) into the other buffer and at once re-issues that quad's load for
+    // tile kt+3 into the same registers, so every global load has two full K-steps (~6000 cycles)
+    // to land.  Tiles past the end load zeros (out-of-range buffer offsets fetch nothing), which
+    // also lets the loop run an even number of steps.
+    auto kstep = [&](int kt, auto s_) {
+        constexpr int S = decltype(s_)::value;
         const int cur = kt & 1;
-        const bool more = (kt + 1) < nk;
         int ao = a_row + cur * (3 * PLANE), bo = b_row + cur * (3 * PLANE);
         asm volatile("" : "+v"(ao), "+v"(bo));          // keep fragment addresses base + immediate
         const __bf16* a = As + ao;
         const __bf16* b = Bs + bo;
-        if (more) load_tile(kbeg + (kt + 1) * BK, S0{});
+        // coordinates of tile kt+2 (consumed by the loads re-issued below)
+        next_coords(kbeg + (kt + 3) * BK);
         static_for<0, 2>([&](auto ip_) {
             constexpr int ip = decltype(ip_)::value;
             bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
@@ -250,23 +281,45 @@ __global__ void __launch_bounds__(256) wgrad3_kernel(const Wgrad3Params p) {
                     bm[c ^ 1] = *reinterpret_cast<const bf16x8*>(b + PLANE + (j + 1) * 32 * PITCH);
                     bl[c ^ 1] = *reinterpret_cast<const bf16x8*>(b + 2 * PLANE + (j + 1) * 32 * PITCH);
                 }
-                if constexpr (ip == 1 && j == 2) { if (more) store_tile(cur ^ 1, S0{}); }
-                static_for<0, 2>([&](auto ii_) {
-                    constexpr int ii = decltype(ii_)::value;
-                    constexpr int i = 2 * ip + ii;
-                    f32x16 cc = acc[i][j];
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ii], bh[c], cc, 0, 0, 0);   // small terms first
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ii], bl[c], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ii], bm[c], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ii], bh[c], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ii], bm[c], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ii], bh[c], cc, 0, 0, 0);
-                    acc[i][j] = cc;
-                });
+                // Program order is pinned with scheduling barriers: the matrix pipe is busy 32
+                // cycles per MFMA, so one ~5-instruction stage of the staging work (split, LDS
+                // store, re-issued load) sits behind each of the first MFMAs instead of behind all 12.
+                unsigned pk[6];
+                auto stage = [&](auto k_) {
+                    constexpr int k = decltype(k_)::value;
+#if !defined(W3_DBG_NOSTAGE)
+                    if constexpr (k >= 1 && k <= 4) {
+                        if constexpr (ip == 0) split_stage<k - 1>(areg[S][j], pk);
+                        else                   split_stage<k - 1>(breg[S][j], pk);
+                    }
+                    if constexpr (k == 5) store_planes(ip == 0 ? As : Bs, cur ^ 1, j_, pk);
+                    if constexpr (k == 6) { if constexpr (ip == 0) load_a(s_, j_); else load_b(s_, j_); }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                f32x16 c0 = acc[2 * ip][j], c1 = acc[2 * ip + 1][j];
+                // small terms first; the two accumulator chains interleaved
+#define W3_MFMA(K0, A, B)                                                                  \
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[c], c0, 0, 0, 0);     \
+                stage(std::integral_constant<int, K0>{});                                  \
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[c], c1, 0, 0, 0);     \
+                stage(std::integral_constant<int, K0 + 1>{});
+                W3_MFMA(0, al, bh)
+                W3_MFMA(2, ah, bl)
+                W3_MFMA(4, am, bm)
+                W3_MFMA(6, am, bh)
+                W3_MFMA(8, ah, bm)
+                W3_MFMA(10, ah, bh)
+#undef W3_MFMA
+                acc[2 * ip][j] = c0; acc[2 * ip + 1][j] = c1;
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
         __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        kstep(kt, S1{});
+        kstep(kt + 1, S0{});
     }
 
     float* o = p.out + (long long)split * p.M * p.Nn;

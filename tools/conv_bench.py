@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--shapes", default="l3c2_3x3d2,l3c3_1x1,l3c1_1x1,aspp_3x3d12,ds_3x3")
     ap.add_argument("--passes", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--check", action="store_true", help="compare with torch CPU conv on a slice")
+    ap.add_argument("--check", action="store_true", help="compare all three passes with torch's GPU conv on the full shape")
+    ap.add_argument("--zeros", action="store_true",
+                    help="all-zero operands: same instruction stream at much lower switching power")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.shapes.split(","):
@@ -52,6 +54,8 @@ def main():
         w = torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5
         y = ops.conv2d_fwd(x, w, None, s, p, d)
         dy = torch.randn_like(y)
+        if args.zeros:
+            x.zero_(); w.zero_(); dy.zero_()
         flops = 2.0 * N * Cout * y.shape[2] * y.shape[3] * Cin * k * k
         res = {}
         if "fwd" in args.passes:
@@ -62,12 +66,16 @@ def main():
             res["wgrad"] = bench(lambda: ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, d), args.iters)
         line = f"{name:14s} " + "  ".join(f"{k_}: {v:7.3f} ms {flops / v / 1e9:6.1f} TF" for k_, v in res.items())
         print(line, flush=True)
-        if args.check:
-            xs, ws = x[:1, :, :32].cpu().double(), w.cpu().double()
-            ref = torch.nn.functional.conv2d(xs, ws, None, s, p, d)
-            got = ops.conv2d_fwd(x[:1, :, :32].contiguous(), w, None, s, p, d).cpu().double()
-            print("   fwd rel err", ((got - ref).norm() / ref.norm()).item())
-
+        if args.check:   # full shape against torch's own (MIOpen, fp32) convolution on the GPU
+            def rel(a, b):
+                return ((a.double() - b.double()).norm() / b.double().norm()).item()
+            xr = x.clone().requires_grad_(True)
+            wr = w.clone().requires_grad_(True)
+            yr = torch.nn.functional.conv2d(xr, wr, None, s, p, d)
+            gx, gw = torch.autograd.grad(yr, (xr, wr), dy)
+            print(f"   vs torch: fwd {rel(ops.conv2d_fwd(x, w, None, s, p, d), yr):.2e}"
+                  f"  dgrad {rel(ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d), gx):.2e}"
+                  f"  wgrad {rel(ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, d)[0], gw):.2e}", flush=True)
 
 if __name__ == "__main__":
     main()
