@@ -395,7 +395,7 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     if (rc) return rc;
     if (!x || !w || !y) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
-    if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))
+    if (!bias && igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                                y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                                d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, -d->pad, d->dil, 0,

@@ -46,7 +46,6 @@ constexpr unsigned kMaxRecords = 0x7ffffffcu;
 struct Igemm3Params {
     const float* in;
     const __bf16* wp3;   // [T][CkP/16][3][Mpad][16]
-    const float* bias;
     float* out;
     long long in_nstride, out_nstride;
     int N, M, Mpad, Ck, CkP;
@@ -126,7 +125,8 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* lo, const __bf16* hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TAPS>
+// ACC: dx += result (gradient fan-in of a residual branch); only the epilogue differs.
+template <int TAPS, bool ACC>
 __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_i3[];
     __bf16* As = smem_i3;                // [2][3][BM][APITCH]
@@ -190,6 +190,9 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
             const int hh = bh[e] + offh, ww = bw[e] + offw;
             const bool ok = pv[e] && hh >= 0 && ww >= 0 && hh < p.Hi && ww < p.Wi;
             boff[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+#if defined(I3_DBG_NOLOADB)
+            boff[e] = kOob;
+#endif
         }
         const bool none = boff[0] == kOob && boff[1] == kOob && boff[2] == kOob && boff[3] == kOob;
         const bool run = boff[0] != kOob && boff[1] == boff[0] + 4u && boff[2] == boff[0] + 8u &&
@@ -346,8 +349,54 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane (l31, lhi) holds, per (i, j), column pix_j of 16 rows
+    // ---- epilogue: lane (l31, lhi) holds, per (i, j), column 32j + l31 of 16 rows
     float* o_img = p.out + (long long)img * p.out_nstride;
+#if defined(I3_DBG_NOSTORE)
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    if (m0 + BM <= p.M && p0 + BN <= p.P) {
+        // interior tile (block-uniform): 128-byte coalesced dword stores whose row offsets are
+        // scalar (soffset) and column offsets immediates — no per-store vector arithmetic
+        // (the descriptor must be built from block-uniform values only: wave-dependent terms make
+        // the compiler wrap every store in a readfirstlane loop)
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            o_img + (long long)m0 * p.P + p0, 0, kMaxRecords, 0x00020000);
+        unsigned voff = (unsigned)((wm * 128 + 4 * lhi) * p.P + wn * 128 + l31) * 4u;
+        asm volatile("" : "+v"(voff));
+        const unsigned P4 = (unsigned)p.P * 4u;
+        static_for<0, 4>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            static_for<0, 2>([&](auto hf_) {       // 8 rows x 4 column tiles per batch
+                constexpr int hf = decltype(hf_)::value;
+                float old[8][4];
+                if constexpr (ACC) {
+                    static_for<0, 8>([&](auto rr_) {
+                        constexpr int r = 8 * hf + decltype(rr_)::value;
+                        constexpr int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                        static_for<0, 4>([&](auto j_) {
+                            constexpr int j = decltype(j_)::value;
+                            old[r - 8 * hf][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                o_rsrc, voff + 128u * j, (unsigned)row * P4, 0));
+                        });
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                static_for<0, 8>([&](auto rr_) {
+                    constexpr int r = 8 * hf + decltype(rr_)::value;
+                    constexpr int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    static_for<0, 4>([&](auto j_) {
+                        constexpr int j = decltype(j_)::value;
+                        float v = acc[i][j][r];
+                        if constexpr (ACC) v += old[r - 8 * hf][j];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc,
+                                                              voff + 128u * j, (unsigned)row * P4, 0);
+                    });
+                });
+                if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        return;
+    }
     int pix = p0 + wn * 128 + l31;
     asm volatile("" : "+v"(pix));
 #pragma unroll
@@ -357,13 +406,12 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
             const int m = m0 + wm * 128 + i * 32 + row;
             if (m >= p.M) continue;
-            const float bsv = p.bias ? p.bias[m] : 0.f;
             float* dst = o_img + (long long)m * p.P + pix;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (pix + 32 * j < p.P) {
-                    float v = acc[i][j][r] + bsv;
-                    if (p.accumulate) v += dst[32 * j];
+                    float v = acc[i][j][r];
+                    if constexpr (ACC) v += dst[32 * j];
                     dst[32 * j] = v;
                 }
             }
@@ -386,7 +434,8 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
     Igemm3Params p;
-    p.in = in; p.bias = bias; p.out = out;
+    if (bias) return DCFP_E_UNSUPPORTED;   // callers route bias convs to the fp32 kernel
+    p.in = in; p.out = out;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, BK); p.Mpad = round_up(M, BM);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
@@ -411,14 +460,16 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
     const long long blocks = groups * 8 * p.tiles_m;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const size_t lds = (size_t)(2 * ABUF + 2 * BBUF) * sizeof(__bf16);
-    auto k1 = igemm3_kernel<1>;
-    auto k9 = igemm3_kernel<9>;
-    const void* kern = T == 1 ? reinterpret_cast<const void*>(k1) : reinterpret_cast<const void*>(k9);
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (T == 1) e = accumulate ? launch(igemm3_kernel<1, true>) : launch(igemm3_kernel<1, false>);
+    else        e = accumulate ? launch(igemm3_kernel<9, true>) : launch(igemm3_kernel<9, false>);
     if (e != hipSuccess) return (int)e;
-    if (T == 1)
-        hipLaunchKernelGGL(igemm3_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL(igemm3_kernel<9>, dim3((unsigned)blocks), dim3(256), lds, stream, p);
     DCFP_RETURN_LAUNCH();
 }

@@ -1,0 +1,93 @@
+"""Parity of the opt-in 3-way bf16 split conv kernels (DCFP_CONV_MATH=bf16x3: conv_igemm3.hip,
+conv_wgrad3.hip) against fp64 CPU convolutions, at the SAME tolerances as the exact-fp32 kernels
+(test_ops_gpu.py).  The library reads the switch once, so the checks run in a child process; the
+shapes are large enough to route to the split kernels (asserted through dcfp_conv2d_kernel_name)
+and cover ragged edges: channel counts off the 16/256 grid, pixel counts off the 256 grid, image
+borders with padding > dilation reach, accumulate-dgrad."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, Cin, H, W, Cout, k, pad, dil
+    (2, 264, 100, 132, 320, 3, 2, 2),     # ragged M (320/264), K (264), P (13200): generic epilogue
+    (2, 256, 128, 256, 512, 1, 0, 1),     # interior tiles only: fast epilogue
+    (2, 272, 128, 200, 256, 3, 12, 12),   # ASPP-like dilation, whole taps in the padding
+    (2, 256, 100, 256, 256, 3, 1, 1),     # unaligned +-1 taps (4 x dword loads on row ends)
+]
+
+
+def _child():
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dcfp_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    out = []
+
+    def rel(a, b):
+        a = a.double().cpu(); b = b.double().cpu()
+        return ((a - b).norm() / b.norm()).item()
+
+    for (N, Cin, H, W, Cout, k, p, d) in CASES:
+        g = torch.Generator().manual_seed(99)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        x = torch.relu(x) + 0.05 * x                       # post-ReLU-like statistics
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        desc = ops._desc(x.shape, w.shape, 1, p, d)
+        names = [ops.conv_kernel_name(desc, wh) for wh in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)]
+        xg, wg = x.to(dev), w.to(dev)
+        y = ops.conv2d_fwd(xg, wg, None, 1, p, d)
+        dy = torch.randn(y.shape, generator=g) * 1e-2
+        dyg = dy.to(dev)
+        dx = ops.conv2d_dgrad(dyg, wg, tuple(x.shape), 1, p, d)
+        seed = torch.randn(x.shape, generator=g)
+        dxa = seed.to(dev)
+        ops.conv2d_dgrad(dyg, wg, tuple(x.shape), 1, p, d, out=dxa, accumulate=True)
+        dw = ops.conv2d_wgrad(dyg, xg, tuple(w.shape), 1, p, d)[0]
+        torch.cuda.synchronize()
+        # fp64 reference on a slice of output channels (forward / wgrad) or input channels (dgrad)
+        mo = slice(Cout - 40, Cout)                        # includes the ragged last M tile
+        y64 = F.conv2d(x.double(), w[mo].double(), None, 1, p, d)
+        ci = slice(Cin - 24, Cin)
+        x64 = x[:, ci].double().requires_grad_(True)
+        w64 = w[:, ci].double().requires_grad_(True)
+        F.conv2d(x64, w64, None, 1, p, d).backward(dy.double())
+        out.append({
+            "case": [N, Cin, H, W, Cout, k, p, d], "kernels": names,
+            "fwd": rel(y[:, mo], y64), "dgrad": rel(dx[:, ci], x64.grad),
+            "dgrad_acc": rel(dxa[:, ci], x64.grad + seed[:, ci].double()),
+            "wgrad": rel(dw[:, ci], w64.grad),
+        })
+    print("BF16X3_RESULT " + json.dumps(out))
+
+
+def test_bf16x3_conv_parity(cuda):
+    env = dict(os.environ, DCFP_CONV_MATH="bf16x3")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("BF16X3_RESULT ")][-1]
+    res = json.loads(line[len("BF16X3_RESULT "):])
+    assert len(res) == len(CASES)
+    assert sum(rec["kernels"][2].startswith("wgrad3_kernel") for rec in res) >= 2, res
+    for rec in res:
+        N, Cin, H, W, Cout, k, p, d = rec["case"]
+        assert rec["kernels"][0].startswith("igemm3_kernel"), rec
+        assert rec["kernels"][1].startswith("igemm3_kernel"), rec
+        K = Cin * k * k
+        tol = 3e-6 * max(1.0, math.sqrt(K) / 8)            # as test_conv_fwd_dgrad_wgrad
+        assert rec["fwd"] < tol, rec
+        assert rec["dgrad"] < max(tol, 1e-5), rec
+        assert rec["dgrad_acc"] < max(tol, 1e-5), rec
+        assert rec["wgrad"] < 2e-5, rec
+
+
+if __name__ == "__main__" and "--child" in sys.argv:
+    _child()
