@@ -204,8 +204,10 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
     }
 }
 
+// o3 (nullable): dgamma = sum(dy*(x-mean)) * rsqrt(var + eps), saving the caller three launches
 __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict__ part,
-                                     float* __restrict__ o1, float* __restrict__ o2) {
+                                     float* __restrict__ o1, float* __restrict__ o2,
+                                     const float* __restrict__ var, float eps, float* __restrict__ o3) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double S1 = 0.0, S2 = 0.0;
@@ -215,6 +217,19 @@ __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict_
     }
     o1[c] = (float)S1;
     o2[c] = (float)S2;
+    if (o3) o3[c] = (float)S2 * rsqrtf(var[c] + eps);
+}
+
+// running = (1-m)*running + m*stat, variance unbiased by count/(count-1) (nn.BatchNorm2d training)
+__global__ void bn_running_kernel(int C, const float* __restrict__ mean, const float* __restrict__ var,
+                                  float momentum, float count, const float* __restrict__ count_dev,
+                                  float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float n = count_dev ? count_dev[0] : count;
+    const float unb = n / fmaxf(n - 1.0f, 1.0f);
+    rmean[c] = rmean[c] * (1.0f - momentum) + momentum * mean[c];
+    rvar[c] = rvar[c] * (1.0f - momentum) + momentum * (var[c] * unb);
 }
 
 // ---- backward stage 2
@@ -341,8 +356,9 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
                                       const float* y, int64_t y_nstride, const float* mean,
                                       const float* var, const float* gamma, const float* beta,
                                       float eps, int relu, int N, int C, int HW, float* sum_dy,
-                                      float* sum_dy_xmu, void* workspace, size_t workspace_bytes,
-                                      dcfp_stream_t stream) {
+                                      float* sum_dy_xmu, float* dgamma, void* workspace,
+                                      size_t workspace_bytes, dcfp_stream_t stream) {
+    if (dgamma && !var) return DCFP_E_BADDESC;
     if (!dy || !x || !mean || !sum_dy || !sum_dy_xmu || N <= 0 || C <= 0 || HW <= 0)
         return DCFP_E_BADDESC;
     if (relu < 0 || relu > 2) return DCFP_E_BADDESC;
@@ -366,7 +382,17 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
     else     { if (relu == 2) LAUNCH_RED(false, 2); else if (relu == 1) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
     hipLaunchKernelGGL(bn_pair_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C,
-                       p.chunks, part, sum_dy, sum_dy_xmu);
+                       p.chunks, part, sum_dy, sum_dy_xmu, var, eps, dgamma);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_bn_update_running_f32(const float* mean, const float* var, int C, float momentum,
+                                          float count, const float* count_dev, float* running_mean,
+                                          float* running_var, dcfp_stream_t stream) {
+    if (!mean || !var || !running_mean || !running_var || C <= 0 || (!count_dev && !(count > 0.f)))
+        return DCFP_E_BADDESC;
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C, mean,
+                       var, momentum, count, count_dev, running_mean, running_var);
     DCFP_RETURN_LAUNCH();
 }
 

@@ -219,14 +219,14 @@ def bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu):
     dy, dns = _batch_strided(dy)
     L = _lib.lib()
     ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
-    s1 = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    s2 = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    s = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
+    s1, s2, dgamma = s[0], s[1], s[2]
     _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu == 1 else 0.0)) * x.numel(), lambda: check(
         L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu == 1 else None, 0, _p(mean), _p(var),
                                  _p(gamma), _p(beta), float(eps), int(relu), N, Cc, H * W, _p(s1), _p(s2),
-                                 _p(ws), ws.numel(), _stream()),
+                                 _p(dgamma), _p(ws), ws.numel(), _stream()),
         "bn_bwd_reduce"))
-    return s1, s2
+    return s1, s2, dgamma
 
 
 def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_residual):
@@ -293,13 +293,10 @@ def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, t
         if group is not None:
             mean, var, count = sync_bn_stats(mean, var, count, group)
         if running_mean is not None and momentum is not None:
-            with torch.no_grad():
-                if isinstance(count, torch.Tensor):
-                    unbiased = var * (count / (count - 1.0).clamp_(min=1.0))
-                else:
-                    unbiased = var * (count / max(count - 1.0, 1.0))
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
+            cdev = count if isinstance(count, torch.Tensor) else None
+            check(_lib.lib().dcfp_bn_update_running_f32(
+                _p(mean), _p(var), Cc, float(momentum), 0.0 if cdev is not None else float(count),
+                _p(cdev), _p(running_mean), _p(running_var), _stream()), "bn_update_running")
     else:
         mean, var = running_mean, running_var
     y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
@@ -313,8 +310,7 @@ def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res
     is re-derived from x inside the kernels (pass y=None)."""
     mean, var, count, group = state
     relu = (1 if y is not None else 2) if relu else 0
-    s1, s2 = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu)
-    dgamma = s2 * torch.rsqrt(var + eps)
+    s1, s2, dgamma = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu)
     dbeta = s1
     if training:
         r1, r2 = sync_bn_bwd_sums(s1, s2, group) if group is not None else (s1, s2)

@@ -60,6 +60,24 @@ class FusedSGD(torch.optim.Optimizer):
         self._tables[gi] = (key, dev, len(params), chunk)
         return dev, len(params), chunk
 
+    def zero_grad(self, set_to_none: bool = True):
+        """Same contract as torch.optim.Optimizer.zero_grad; the in-place variant (what torch 1.10's
+        default did, train.py:256) zeroes all gradients with a few multi-tensor launches instead
+        of one fill per parameter."""
+        if set_to_none:
+            return super().zero_grad(set_to_none=True)
+        grads = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    if p.grad.grad_fn is not None:
+                        p.grad.detach_()
+                    else:
+                        p.grad.requires_grad_(False)
+                    grads.append(p.grad)
+        if grads:
+            torch._foreach_zero_(grads)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -117,8 +117,14 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                            const float* y, int64_t y_nstride, const float* mean,
                            const float* var, const float* gamma, const float* beta, float eps,
                            int relu, int N, int C, int HW,
-                           float* sum_dy, float* sum_dy_xmu,
+                           float* sum_dy, float* sum_dy_xmu, float* dgamma /* nullable: sum_dy_xmu*istd */,
                            void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
+/* Running statistics of nn.BatchNorm2d in training mode (resnet.py:9, momentum 0.1):
+ * running = (1-momentum)*running + momentum*stat, the variance unbiased by count/(count-1);
+ * count_dev (nullable, one float) overrides `count` (SyncBN: global count on the device). */
+int dcfp_bn_update_running_f32(const float* mean, const float* var, int C, float momentum,
+                               float count, const float* count_dev, float* running_mean,
+                               float* running_var, dcfp_stream_t stream);
 /* Backward stage 2: dx = gamma*istd*( g - sum_dy/M - (x-mean)*istd^2*sum_dy_xmu/M ),
  * M = count (N*HW); under SyncBN the global count lives on the device: count_dev (nullable,
  * one float) then overrides `count` without a host round trip.  d_residual (nullable) = g. */
