@@ -220,6 +220,31 @@ __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict_
     if (o3) o3[c] = (float)S2 * rsqrtf(var[c] + eps);
 }
 
+// SyncBatchNorm forward combine: allv[r] = (mean_r[C], var_r[C], count_r) gathered from every rank ->
+// pooled mean / biased variance over all ranks' pixels (parallel-variance combination), one launch
+__global__ void syncbn_combine_kernel(const float* __restrict__ allv, int world, int C,
+                                      float* __restrict__ gmean, float* __restrict__ gvar,
+                                      float* __restrict__ total) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int S = 2 * C + 1;
+    double tot = 0.0, m = 0.0, v = 0.0;
+    for (int r = 0; r < world; ++r) {
+        const double n = (double)allv[(long long)r * S + 2 * C];
+        tot += n;
+        m += (double)allv[(long long)r * S + c] * n;
+    }
+    m /= tot;
+    for (int r = 0; r < world; ++r) {
+        const double n = (double)allv[(long long)r * S + 2 * C];
+        const double d = (double)allv[(long long)r * S + c] - m;
+        v += ((double)allv[(long long)r * S + C + c] + d * d) * n;
+    }
+    gmean[c] = (float)m;
+    gvar[c] = (float)(v / tot);
+    if (c == 0) total[0] = (float)tot;
+}
+
 // running = (1-m)*running + m*stat, variance unbiased by count/(count-1) (nn.BatchNorm2d training)
 __global__ void bn_running_kernel(int C, const float* __restrict__ mean, const float* __restrict__ var,
                                   float momentum, float count, const float* __restrict__ count_dev,
@@ -425,5 +450,13 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
     if (vec) { if (relu == 2) LAUNCH_APP(true, 2); else if (relu == 1) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
     else     { if (relu == 2) LAUNCH_APP(false, 2); else if (relu == 1) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
 #undef LAUNCH_APP
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean, float* var,
+                                       float* total_count, dcfp_stream_t stream) {
+    if (!gathered || !mean || !var || !total_count || world <= 0 || C <= 0) return DCFP_E_BADDESC;
+    hipLaunchKernelGGL(syncbn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream),
+                       gathered, world, C, mean, var, total_count);
     DCFP_RETURN_LAUNCH();
 }

@@ -255,25 +255,51 @@ def _sync_group(group):
     return g if g is not None else dist.group.WORLD
 
 
+_COUNT_CACHE = {}
+
+
+def _count_tensor(count, device):
+    """Per-rank pixel count as a one-float device tensor, uploaded once per distinct value (a fresh
+    torch.tensor(..., device=cuda) per BN layer is a blocking H2D copy: 115 pipeline drains per step)."""
+    key = (float(count), str(device))
+    t = _COUNT_CACHE.get(key)
+    if t is None:
+        t = torch.tensor([float(count)], device=device, dtype=torch.float32)
+        _COUNT_CACHE[key] = t
+    return t
+
+
 def sync_bn_stats(mean, var, count, group):
     """SyncBatchNorm forward exchange (engine.py:65): ONE all_gather of [mean, var, count]
     (2C+1 floats per rank), then the pooled mean / biased variance over all ranks' pixels
-    (parallel-variance combination), identical on every rank."""
+    (parallel-variance combination), identical on every rank; the total count stays on the device."""
     Cc = mean.numel()
     world = dist.get_world_size(group)
-    local = torch.cat([mean, var, torch.tensor([float(count)], device=mean.device, dtype=mean.dtype)])
+    local = torch.cat([mean, var, _count_tensor(count, mean.device)])
     allv = torch.empty(world, local.numel(), device=mean.device, dtype=mean.dtype)
     dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group)
+    if mean.is_cuda:
+        out = torch.empty(2 * Cc + 1, device=mean.device, dtype=torch.float32)
+        check(_lib.lib().dcfp_syncbn_combine_f32(_p(allv), world, Cc, _p(out), _p(out[Cc:]), _p(out[2 * Cc:]),
+                                                 _stream()), "syncbn_combine")
+        return out[:Cc], out[Cc:2 * Cc], out[2 * Cc:]
+    # host tensors (the gloo rehearsal of the exchange in tests/test_distributed_cpu.py)
     means, vars_, counts = allv[:, :Cc], allv[:, Cc:2 * Cc], allv[:, 2 * Cc:]
     total = counts.sum()
     gmean = (means * counts).sum(0) / total
     gvar = ((vars_ + (means - gmean) ** 2) * counts).sum(0) / total
-    return gmean.contiguous(), gvar.contiguous(), total.reshape(1).contiguous()  # no host sync
+    return gmean.contiguous(), gvar.contiguous(), total.reshape(1).contiguous()
 
 
 def sync_bn_bwd_sums(s1, s2, group):
-    """SyncBatchNorm backward exchange: ONE all_reduce(SUM) of [sum g, sum g*(x-mean)] (2C floats)."""
+    """SyncBatchNorm backward exchange: ONE all_reduce(SUM) of [sum g, sum g*(x-mean)] (2C floats);
+    bn_bwd_reduce returns the two rows adjacent in one buffer, which is then reduced in place."""
     Cc = s1.numel()
+    if (s1.is_contiguous() and s2.is_contiguous() and s1.untyped_storage().data_ptr() == s2.untyped_storage().data_ptr()
+            and s2.storage_offset() == s1.storage_offset() + Cc):
+        both = s1.as_strided((2 * Cc,), (1,), s1.storage_offset())
+        dist.all_reduce(both, group=group)
+        return s1, s2
     both = torch.cat([s1, s2])
     dist.all_reduce(both, group=group)
     return both[:Cc].contiguous(), both[Cc:].contiguous()
@@ -311,7 +337,8 @@ def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res
     mean, var, count, group = state
     relu = (1 if y is not None else 2) if relu else 0
     s1, s2, dgamma = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu)
-    dbeta = s1
+    # the SyncBN exchange reduces (s1, s2) in place; dbeta stays this rank's sum
+    dbeta = s1.clone() if (training and group is not None) else s1
     if training:
         r1, r2 = sync_bn_bwd_sums(s1, s2, group) if group is not None else (s1, s2)
     else:  # running statistics are constants: dx = g * gamma * istd

@@ -119,6 +119,11 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                            int relu, int N, int C, int HW,
                            float* sum_dy, float* sum_dy_xmu, float* dgamma /* nullable: sum_dy_xmu*istd */,
                            void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
+/* SyncBatchNorm (engine.py:65) forward exchange, device side: `gathered` = world rows of
+ * (mean[C], var[C], count) as all-gathered from the ranks -> pooled mean, biased variance over all
+ * ranks' pixels and the total count (one float, stays on the device). */
+int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean, float* var,
+                            float* total_count, dcfp_stream_t stream);
 /* Running statistics of nn.BatchNorm2d in training mode (resnet.py:9, momentum 0.1):
  * running = (1-momentum)*running + momentum*stat, the variance unbiased by count/(count-1);
  * count_dev (nullable, one float) overrides `count` (SyncBN: global count on the device). */
