@@ -54,13 +54,16 @@ def synthetic_batch(n, h, w, seed, device):
     return images.to(device), labels.to(device)
 
 
-def build_model(backbone, device):
+def build_model(backbone, device, channel_cfg=None):
     from dcfp_amd import networks
     from dcfp_amd.loss.criterion import build_criterions
     crit = build_criterions("ce", _DS(), {"ds_weight": 0.4})
     bb = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
     model = networks.deeplabv3.Seg_Model(backbone=backbone, backbone_para=bb, model_para={}, num_classes=19,
                                          align_corner=True, criterion=crit, deepsup=True)
+    if channel_cfg:   # slim model of a prune.py run (pruners/channel_pruner.py:29-74)
+        from dcfp_amd import pruners
+        pruners.init_pruned_model(model, torch.load(channel_cfg, weights_only=False))
     return model.to(device).train()
 
 
@@ -175,6 +178,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", default="2,512,1024", help="n,h,w of the CPU baseline sample")
+    ap.add_argument("--channel-cfg", default=None,
+                    help="time the slim model described by this channel_cfg.pth instead (not the headline config)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra leg that re-times the step with DCFP_CONV_MATH=bf16x3")
     ap.add_argument("--force-ddp", action="store_true",
@@ -202,7 +207,7 @@ def main():
     from dcfp_amd import optimizer as opt, pruners, ops
     from dcfp_amd.engine import Engine
     torch.manual_seed(12345 + rank)           # train.py:166-171
-    seg_model = build_model(args.backbone, device)
+    seg_model = build_model(args.backbone, device, args.channel_cfg)
     optimizer = opt.build_optimizer(_OptArgs, seg_model)
     optimizer.zero_grad()
     train_pruning = pruners.dcfp_pruning(seg_model, 0.999)
@@ -269,7 +274,7 @@ def main():
     # reads the switch once per process, so the leg runs in a child after this process let go of
     # its device memory.
     alt = None
-    if (rank == 0 and world == 1 and not args.no_alt and not args.force_ddp
+    if (rank == 0 and world == 1 and not args.no_alt and not args.force_ddp and not args.channel_cfg
             and os.environ.get("DCFP_CONV_MATH", "") == ""):
         del model, seg_model, optimizer, train_pruning, images, labels
         import gc
@@ -295,11 +300,12 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if os.environ.get("DCFP_CONV_MATH", "") in ("", "f32") else "f32 via bf16x3 split",
                "data": "synthetic",
-               "config": {"workload": f"DeepLabv3-{args.backbone}+ASPP os8, {args.batch}x3x{H}x{W} per GPU, "
+               "config": {"workload": ("PRUNED (" + args.channel_cfg + ") " if args.channel_cfg else "") +
+                                      f"DeepLabv3-{args.backbone}+ASPP os8, {args.batch}x3x{H}x{W} per GPU, "
                                       "CE+0.4*deepsup CE (fused upsample), SyncBN+DDP, EIC step, SGD m0.9 wd5e-4",
                           "global_batch": global_batch, "parallelism": f"dp{world}"},
                "final_loss": last, "peak_mem_GiB": peak_mem,
-               "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone) == (1024, 2048, "resnet101") else None,
+               "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone, args.channel_cfg) == (1024, 2048, "resnet101", None) else None,
                "roofline": roof, "cpu_baseline": cpu, "alt_math": alt, "detail": extra}
         print(json.dumps(out))
     if dist.is_initialized():

@@ -25,6 +25,10 @@ SHAPES = {
     "stem3_3x3": (4, 64, 512, 1024, 128, 3, 1, 1, 1),
     "l1c2_3x3": (4, 64, 256, 512, 64, 3, 1, 1, 1),
     "l2c2_3x3": (4, 128, 128, 256, 128, 3, 1, 1, 1),
+    # layer3 block after a 60 %-FLOPs prune (tools/pipeline_cfg5.sh): widths off every tile grid
+    "p_l3c1_1x1": (4, 1024, 128, 256, 236, 1, 1, 0, 1),
+    "p_l3c2_3x3d2": (4, 236, 128, 256, 232, 3, 1, 2, 2),
+    "p_l3c3_1x1": (4, 232, 128, 256, 1024, 1, 1, 0, 1),
 }
 
 

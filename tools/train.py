@@ -8,6 +8,7 @@ import json
 import os
 import os.path as osp
 import sys
+import time
 
 sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
 import torch  # noqa: E402
@@ -59,6 +60,8 @@ def get_parser():
     p.add_argument("--loss-para", type=str, default="{}")
     p.add_argument("--prune-type", type=str, default=None)
     p.add_argument("--channel-cfg", type=str, default=None)
+    p.add_argument("--log-time", type=str2bool, default="False",
+                   help="synchronise after every iteration and print its device time (batch synthesis excluded)")
     return p
 
 
@@ -113,6 +116,9 @@ def main(argv=None):
         per_rank = max(1, args.batch_size // engine.world_size)
         for it in range(args.start_iters, args.num_steps):
             images, labels = dataset.batch(per_rank, device)
+            if args.log_time:
+                torch.cuda.synchronize()
+                t_it = time.perf_counter()
             if "gsrl" in args.loss_type:   # fine-tune stage: {'ori', 'weight'} labels (datasets/Base.py:73-89)
                 labels = {"ori": labels, "weight": 1.0 + (labels % 3 == 0).float()}
             optimizer.zero_grad()
@@ -124,6 +130,11 @@ def main(argv=None):
             if train_pruning is not None:
                 train_pruning.step(seg_model)
             optimizer.step()
+            if args.log_time:
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t_it) * 1e3
+                if main_flag:
+                    print("  step %.1f ms  %.2f images/s/GPU" % (ms, per_rank / ms * 1e3), flush=True)
             if main_flag:
                 print("Iters%d/%d lr=%.2e loss=%.4f" % (it + 1, args.num_steps, lr, reduce_loss.item()), flush=True)
                 done = it + 1
