@@ -175,10 +175,11 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
 
     unsigned boff[4];            // per-pixel byte offsets of the loader's current tap (kOob = padding)
     bool bvec = false;           // the 4 pixels are one contiguous in-image run (or all padding)
-    int ld_t = 0, ld_cb = 0;     // (tap, channel block) of the tile the loader fetches next
+    int ld_t = 0, ld_cb = 0;     // (tap, channel block) of the tile the B loader fetches next
+    int a_tile = 0;              // index (tap-major) of the tile the A loader fetches next
     unsigned a_step = 0;         // byte offset of that tile's first plane in Wp3
     f32x4 areg[6];
-    float breg[4][4];
+    float breg[2][4][4];         // two staging sets: B tiles are fetched two K-steps ahead
 
     auto set_tap = [&](int t) {
         const int kh = (TAPS == 9) ? t / 3 : 0;
@@ -199,9 +200,9 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
                          boff[3] == boff[0] + 12u;
         bvec = none || run;
     };
-    // step the loader to the next tile in tap-major K order; past the last tile B fetches nothing
-    // (out-of-range offsets) and A re-reads the last tile
-    auto advance = [&]() {
+    // step the B loader to the next tile in tap-major K order; past the last tile it fetches
+    // nothing (out-of-range offsets)
+    auto advance_b = [&]() {
         if (++ld_cb == kpt) {
             ld_cb = 0;
             ++ld_t;
@@ -212,9 +213,13 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
                 bvec = true;
             }
         }
-        const int t = ld_t < TAPS ? ld_t : TAPS - 1;
-        const int cb = ld_t < TAPS ? ld_cb : kpt - 1;
-        a_step = (unsigned)(t * kpt + cb) * 3u * a_plane_bytes;
+    };
+    // the A loader runs one K-step ahead only (weights come from L2); past the end it re-reads
+    // the last tile
+    auto advance_a = [&]() {
+        ++a_tile;
+        const int t = a_tile < nk ? a_tile : nk - 1;
+        a_step = (unsigned)t * 3u * a_plane_bytes;
     };
     auto load_a = [&](auto h_) {
         constexpr int h = decltype(h_)::value;
@@ -227,7 +232,8 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
         asm volatile("" : "+v"(so));
         *reinterpret_cast<f32x4*>(As + so + (h >> 1) * APLANE + (h & 1) * 128 * APITCH) = areg[h];
     };
-    auto load_b = [&](auto q_) {
+    auto load_b = [&](auto s_, auto q_) {
+        constexpr int S = decltype(s_)::value;
         constexpr int q = decltype(q_)::value;
         int c = ld_cb * BK + ty + 4 * q;
         c = c < p.Ck ? c : p.Ck - 1;        // rows past Ck meet zero rows of Wp3
@@ -235,11 +241,11 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
         if (bvec) {   // one (possibly unaligned) dwordx4; bit-cast the WHOLE vector (see conv_wgrad.hip)
             const f32x4 v = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[0] + coff, 0, 0));
-            static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; breg[q][e] = v[e]; });
+            static_for<0, 4>([&](auto e_) { constexpr int e = decltype(e_)::value; breg[S][q][e] = v[e]; });
         } else {
             static_for<0, 4>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
-                breg[q][e] = __builtin_bit_cast(
+                breg[S][q][e] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, boff[e] + coff, 0, 0));
             });
         }
@@ -264,90 +270,132 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: tile 0 into LDS buffer 0, the loads of tile 1 in flight
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // prologue: tile 0 into LDS buffer 0; B tiles 1 and 2 and A tile 1 in flight
     set_tap(0);
     static_for<0, 6>([&](auto h_) { load_a(h_); });
-    static_for<0, 4>([&](auto q_) { load_b(q_); });
+    static_for<0, 4>([&](auto q_) { load_b(P0{}, q_); });
+    advance_b();
+    static_for<0, 4>([&](auto q_) { load_b(P1{}, q_); });
     static_for<0, 6>([&](auto h_) { store_a(0, h_); });
     static_for<0, 4>([&](auto q_) {
         constexpr int q = decltype(q_)::value;
         unsigned pk[6];
-        split_stage<0>(breg[q], pk); split_stage<1>(breg[q], pk); split_stage<2>(breg[q], pk);
-        split_stage<3>(breg[q], pk); split_stage<4>(breg[q], pk);
+        split_stage<0>(breg[0][q], pk); split_stage<1>(breg[0][q], pk); split_stage<2>(breg[0][q], pk);
+        split_stage<3>(breg[0][q], pk); split_stage<4>(breg[0][q], pk);
         store_b(0, q_, pk);
     });
-    advance();
+    advance_a();
     static_for<0, 6>([&](auto h_) { load_a(h_); });
-    static_for<0, 4>([&](auto q_) { load_b(q_); });
+    advance_b();
+    static_for<0, 4>([&](auto q_) { load_b(P0{}, q_); });
     __syncthreads();
 
     // fragment addresses (elements): A row-major 16-byte reads, B transposed 8-byte reads
     const int a_frag = (wm * 128 + l31) * APITCH + 8 * lhi;
     const int b_frag = (8 * (lane >> 5) + ((lane & 15) >> 2)) * BPITCH + wn * 128 + 16 * ((lane >> 4) & 1) +
                        4 * (lane & 3);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        int ao = a_frag + cur * ABUF, bo = b_frag + cur * BBUF;
-        asm volatile("" : "+v"(ao), "+v"(bo));          // keep fragment addresses base + immediate
-        const __bf16* a = As + ao;
-        const __bf16* b = Bs + bo;
-        advance();                                      // loader -> tile kt+2
-        bf16x8 af[4][3];                                // [row tile][plane hi, mid, lo]
-        static_for<0, 4>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            static_for<0, 3>([&](auto pl_) {
-                constexpr int pl = decltype(pl_)::value;
-                af[i][pl] = *reinterpret_cast<const bf16x8*>(a + pl * APLANE + i * 32 * APITCH);
-            });
+    bf16x8 af[2][4][3];                                 // [K-step parity][row tile][plane hi, mid, lo]
+    bf16x8 bfr[2][3];                                   // [column tile parity][plane]
+    {
+        const __bf16* a = As + a_frag;
+        const __bf16* b = Bs + b_frag;
+        static_for<0, 12>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            af[0][k / 3][k % 3] = *reinterpret_cast<const bf16x8*>(a + (k % 3) * APLANE + (k / 3) * 32 * APITCH);
         });
-        bf16x8 bfr[2][3];
         static_for<0, 3>([&](auto pl_) {
             constexpr int pl = decltype(pl_)::value;
             bfr[0][pl] = tr_read8(b + pl * BPLANE, b + pl * BPLANE + 4 * BPITCH);
         });
+    }
+
+    // One K-step (PAR = kt & 1 selects the LDS buffer and the A-fragment set it computes on).
+    // Column tiles 0..2 carry the staging of the next tile into the other LDS buffer (B quads
+    // split stage by stage, A chunks copied) and re-issue the loads: B for tile kt+3 into the
+    // register set just drained, A for tile kt+2.  Column tile 3 opens with the step's only
+    // barrier and then reads the NEXT step's A fragments and first B fragments from the other
+    // buffer behind its own MFMAs, so no LDS latency is exposed when the next step begins.
+    auto kstep = [&](int kt, auto par_) {
+        constexpr int PAR = decltype(par_)::value;
+        using SB = std::integral_constant<int, PAR ^ 1>;    // B register set holding tile kt+1
+        int ao = a_frag + (PAR ^ 1) * ABUF, bo = b_frag + PAR * BBUF, bn = b_frag + (PAR ^ 1) * BBUF;
+        asm volatile("" : "+v"(ao), "+v"(bo), "+v"(bn));    // keep fragment addresses base + immediate
+        const __bf16* an = As + ao;     // next step's A image
+        const __bf16* b = Bs + bo;      // this step's B image
+        const __bf16* bnx = Bs + bn;    // next step's B image
+        advance_b();                    // -> tile kt+3
+        advance_a();                    // -> tile kt+2
         static_for<0, 4>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             constexpr int c = j & 1;
-            unsigned pk[6];
+            unsigned pk0[6], pk1[6];
+            if constexpr (j == 3) __syncthreads();
             // the staging stage pinned behind MFMA number k (0..23) of column tile j
             auto stage = [&](auto k_) {
                 constexpr int k = decltype(k_)::value;
-                if constexpr (j < 3 && k < 3) {         // fragments of the next column tile
+                if constexpr (j < 3 && k < 3) {         // this step's fragments of the next column tile
                     bfr[c ^ 1][k] = tr_read8(b + k * BPLANE + (j + 1) * 32,
                                              b + k * BPLANE + 4 * BPITCH + (j + 1) * 32);
                 }
-                if constexpr (k >= 4 && k <= 8) split_stage<k - 4>(breg[j], pk);
-                if constexpr (k == 9) store_b(cur ^ 1, j_, pk);
-                if constexpr (k == 10) load_b(j_);
-                if constexpr (k == 12) store_a(cur ^ 1, j_);
-                if constexpr (k == 13) load_a(j_);
-                constexpr int h2 = j < 2 ? j + 4 : 0;   // column tiles 0 and 1 also carry A chunks 4 and 5
-                if constexpr (j < 2 && k == 15) store_a(cur ^ 1, std::integral_constant<int, h2>{});
-                if constexpr (j < 2 && k == 16) load_a(std::integral_constant<int, h2>{});
+                if constexpr (j < 2) {                  // B quads 2j, 2j+1 and A chunks 2j, 2j+1
+                    using Q0 = std::integral_constant<int, 2 * j>;
+                    using Q1 = std::integral_constant<int, 2 * j + 1>;
+                    if constexpr (k >= 3 && k <= 7) split_stage<k - 3>(breg[PAR ^ 1][2 * j], pk0);
+                    if constexpr (k == 8) store_b(PAR ^ 1, Q0{}, pk0);
+                    if constexpr (k == 9) load_b(SB{}, Q0{});
+                    if constexpr (k >= 10 && k <= 14) split_stage<k - 10>(breg[PAR ^ 1][2 * j + 1], pk1);
+                    if constexpr (k == 15) store_b(PAR ^ 1, Q1{}, pk1);
+                    if constexpr (k == 16) load_b(SB{}, Q1{});
+                    if constexpr (k == 17) store_a(PAR ^ 1, Q0{});
+                    if constexpr (k == 18) load_a(Q0{});
+                    if constexpr (k == 19) store_a(PAR ^ 1, Q1{});
+                    if constexpr (k == 20) load_a(Q1{});
+                }
+                if constexpr (j == 2) {                 // A chunks 4, 5
+                    using H4 = std::integral_constant<int, 4>;
+                    using H5 = std::integral_constant<int, 5>;
+                    if constexpr (k == 3) store_a(PAR ^ 1, H4{});
+                    if constexpr (k == 4) load_a(H4{});
+                    if constexpr (k == 5) store_a(PAR ^ 1, H5{});
+                    if constexpr (k == 6) load_a(H5{});
+                }
+                if constexpr (j == 3) {                 // next step's fragments (after the barrier)
+                    if constexpr (k < 12)
+                        af[PAR ^ 1][k / 3][k % 3] = *reinterpret_cast<const bf16x8*>(
+                            an + (k % 3) * APLANE + (k / 3) * 32 * APITCH);
+                    if constexpr (k >= 12 && k < 15)
+                        bfr[0][k - 12] = tr_read8(bnx + (k - 12) * BPLANE, bnx + (k - 12) * BPLANE + 4 * BPITCH);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             static_for<0, 4>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 f32x16 cc = acc[i][j];
                 // small terms first
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[c][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i][2], bfr[c][0], cc, 0, 0, 0);
                 stage(std::integral_constant<int, 6 * i + 0>{});
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[c][2], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i][0], bfr[c][2], cc, 0, 0, 0);
                 stage(std::integral_constant<int, 6 * i + 1>{});
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[c][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i][1], bfr[c][1], cc, 0, 0, 0);
                 stage(std::integral_constant<int, 6 * i + 2>{});
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[c][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i][1], bfr[c][0], cc, 0, 0, 0);
                 stage(std::integral_constant<int, 6 * i + 3>{});
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[c][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i][0], bfr[c][1], cc, 0, 0, 0);
                 stage(std::integral_constant<int, 6 * i + 4>{});
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[c][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i][0], bfr[c][0], cc, 0, 0, 0);
                 stage(std::integral_constant<int, 6 * i + 5>{});
                 acc[i][j] = cc;
             });
         });
-        __syncthreads();
+    };
+    // an odd tail step multiplies a zero B tile (the loader fetches nothing past the end)
+    for (int kt = 0; kt < nk; kt += 2) {
+        kstep(kt, P0{});
+        kstep(kt + 1, P1{});
     }
+    __syncthreads();
 
     // ---- epilogue: lane (l31, lhi) holds, per (i, j), column 32j + l31 of 16 rows
     float* o_img = p.out + (long long)img * p.out_nstride;
