@@ -1,0 +1,1 @@
+"""Head building blocks of the segmentation networks (ASPP)."""
