@@ -90,7 +90,13 @@ struct Frag<1> {
 
 // ACC: dx += result (gradient fan-in of a residual branch); only the epilogue differs.
 template <int TAPS, int TM, int TN, int WM, int WN, bool SD, bool ACC, int KB = 16>
-__global__ void __launch_bounds__(64 * WM * WN) igemm2_kernel(const Igemm2Params p) {
+// Tiles with <= 128 accumulator registers per lane are built for TWO waves per SIMD (the second
+// launch-bounds argument is waves per execution unit in HIP): the small-Cout layers have 4x the
+// staging work per MFMA of the 256x256 tile, and a second resident block hides it (same-box A/B on
+// the stem / layer1 / layer2 3x3 shapes: +9...+22 %).  The accumulate-epilogue variants are left
+// alone (they would spill).
+__global__ void __launch_bounds__(64 * WM * WN, (TM * TN <= 8 && WM * WN == 4 && !ACC) ? 2 : 1)
+igemm2_kernel(const Igemm2Params p) {
     constexpr int BK = KB;     // shadows the file-level default: K-step depth of this instance
     constexpr int NPART = BK / 4;   // staging is issued in NPART parts over the first NPART MFMA slots
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;

@@ -259,7 +259,9 @@ typedef unsigned int v4u __attribute__((vector_size(16)));
 //    of a K-step instead of running as one serial block in front of the MFMAs,
 //  * rows past M / Nn are clamped instead of predicated (they only feed discarded outputs).
 template <int TAPS, int TM, int TN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) wgrad2_kernel(const WgradParams p) {
+// the 128 x 256 tile (128 accumulator registers) is built for two waves per SIMD, as in conv_igemm2.hip
+__global__ void __launch_bounds__(64 * WM * WN, (TM * TN <= 8 && WM * WN == 4) ? 2 : 1)
+wgrad2_kernel(const WgradParams p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     constexpr int ROWS = NT / 4;
     constexpr int PA = BM / ROWS, PB = BN / ROWS;
@@ -589,6 +591,11 @@ struct Plan {
     int tiles_m, tiles_n, splits, kchunk;
 };
 
+static bool wgrad_v1() {
+    static const bool v = getenv("DCFP_WGRAD_V1") != nullptr;
+    return v;
+}
+
 Plan make_plan(const DcfpConvDesc* d) {
     Plan pl;
     const int M = d->Cout, Nn = d->Cin * d->KH * d->KW;
@@ -603,7 +610,7 @@ Plan make_plan(const DcfpConvDesc* d) {
     // workgroup per CU (512 registers/lane), so tiles*splits just above a multiple of the CU
     // count wastes most of a round (513 blocks on 256 CUs took 1.35x the time of 252).
     const int cus = num_cus();
-    const long long per_cu = pl.cfg == 2 ? 8 : 1;            // resident workgroups per CU
+    const long long per_cu = pl.cfg == 2 ? 8 : (pl.cfg == 1 && !wgrad_v1()) ? 2 : 1;   // resident workgroups per CU
     const long long slots = (long long)cus * per_cu;
     const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);   // >= 8 K-steps per split
     long long splits = 1;
@@ -654,10 +661,6 @@ static bool wgrad3_ok(const DcfpConvDesc* d, int cfg) {
     return math_bf16x3() && cfg == 0 && d->stride == 1 && (d->Wout % 4 == 0);
 }
 
-static bool wgrad_v1() {
-    static const bool v = getenv("DCFP_WGRAD_V1") != nullptr;
-    return v;
-}
 
 template <int TAPS, int TM, int TN, int WM, int WN>
 int launch_cfg(const WgradParams& p, long long blocks, hipStream_t stream) {
