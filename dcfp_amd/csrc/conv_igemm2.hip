@@ -300,8 +300,52 @@ igemm2_kernel(const Igemm2Params p) {
         __syncthreads();
     }
 
-    // ---- epilogue (the opaque asm keeps its 64 row pointers from being hoisted above the K loop)
+    // ---- epilogue
     float* o_img = p.out + (long long)img * p.out_nstride;
+    if constexpr (TN == 4) {
+        // Interior tile of a plain training conv (block-uniform test): 16-byte stores through a
+        // buffer descriptor whose base is block-uniform, row offsets scalar (soffset) and the
+        // lane's column a single VGPR - no per-row predicates or 64-bit address arithmetic.
+        if (m0 + BM <= p.M && p0 + BN <= p.P && p.vec_store && !p.bias && !p.scale && !p.relu) {
+            constexpr unsigned kMaxRec = 0x7ffffffcu;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                o_img + (long long)m0 * p.P + p0, 0, kMaxRec, 0x00020000);
+            unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
+            asm volatile("" : "+v"(voff));
+            const unsigned P4 = (unsigned)p.P * 4u;
+            static_for<0, TM>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                f32x4 old[16];
+                if constexpr (ACC) {   // 16 independent loads in flight, then 16 add+stores
+                    static_for<0, 16>([&](auto r_) {
+                        constexpr int r = decltype(r_)::value;
+                        constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                        old[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            o_rsrc, voff, (unsigned)row * P4, 0));
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                static_for<0, 16>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                    f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if constexpr (ACC) v += old[r];
+                    // The row offset goes into the VGPR offset, NOT the SGPR soffset field: a 16-byte
+                    // buffer store with a register soffset whose data registers are rewritten by
+                    // the next VALU instructions stored the NEW upper half in lanes 12-15 / 28-31
+                    // of each wave half (tools/micro/acc_debug.py pins it; hipcc 7.2 only pads
+                    // the immediate-soffset form of this store-data hazard).
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                        __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                        o_rsrc, voff + (unsigned)row * P4, 0, 0);
+                });
+                if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);
+            });
+            return;
+        }
+    }
+    // general path (edges, bias, fused inference epilogue); the opaque asm keeps its 64 row
+    // pointers from being hoisted above the K loop
     int pix = p0 + wn * (TN * 32) + TN * l31;
     asm volatile("" : "+v"(pix));
     const bool vec = (TN == 4) && p.vec_store && (pix + 3 < p.P);

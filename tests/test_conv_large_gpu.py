@@ -1,9 +1,10 @@
-"""Parity of the opt-in 3-way bf16 split conv kernels (DCFP_CONV_MATH=bf16x3: conv_igemm3.hip,
-conv_wgrad3.hip) against fp64 CPU convolutions, at the SAME tolerances as the exact-fp32 kernels
-(test_ops_gpu.py).  The library reads the switch once, so the checks run in a child process; the
-shapes are large enough to route to the split kernels (asserted through dcfp_conv2d_kernel_name)
-and cover ragged edges: channel counts off the 16/256 grid, pixel counts off the 256 grid, image
-borders with padding > dilation reach, accumulate-dgrad."""
+"""Conv parity at sizes that reach the 256 x 256-tile kernels (test_ops_gpu.py's shapes are too small
+to): the exact-fp32 path (conv_igemm2.hip / conv_wgrad.hip, incl. the interior fast epilogue and the
+pipelined accumulate-dgrad) and the opt-in 3-way bf16 split (DCFP_CONV_MATH=bf16x3: conv_igemm3.hip,
+conv_wgrad3.hip), both against fp64 CPU convolutions at the SAME tolerances.  The library reads the
+switch once, so each mode runs in a child process; routing is asserted through
+dcfp_conv2d_kernel_name.  Covered edges: channel counts off the 16/256 grid, pixel counts off the
+256 grid, image borders with padding > dilation reach, accumulate-dgrad."""
 import json
 import math
 import os
@@ -68,19 +69,22 @@ def _child():
     print("BF16X3_RESULT " + json.dumps(out))
 
 
-def test_bf16x3_conv_parity(cuda):
-    env = dict(os.environ, DCFP_CONV_MATH="bf16x3")
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_large_conv_parity(cuda, mode):
+    env = dict(os.environ, DCFP_CONV_MATH=mode)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("BF16X3_RESULT ")][-1]
     res = json.loads(line[len("BF16X3_RESULT "):])
     assert len(res) == len(CASES)
-    assert sum(rec["kernels"][2].startswith("wgrad3_kernel") for rec in res) >= 2, res
+    fwd_kernel, wgrad_kernel = ("igemm3_kernel", "wgrad3_kernel") if mode == "bf16x3" else \
+        ("igemm2_kernel", "wgrad2_kernel")
+    assert sum(rec["kernels"][2].startswith(wgrad_kernel) for rec in res) >= 2, res
     for rec in res:
         N, Cin, H, W, Cout, k, p, d = rec["case"]
-        assert rec["kernels"][0].startswith("igemm3_kernel"), rec
-        assert rec["kernels"][1].startswith("igemm3_kernel"), rec
+        assert rec["kernels"][0].startswith(fwd_kernel), rec
+        assert rec["kernels"][1].startswith(fwd_kernel), rec
         K = Cin * k * k
         tol = 3e-6 * max(1.0, math.sqrt(K) / 8)            # as test_conv_fwd_dgrad_wgrad
         assert rec["fwd"] < tol, rec
