@@ -220,7 +220,7 @@ def main():
     max_iter = 4000
 
     def step(it):
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad()                 # train.py:256, verbatim (set_to_none under torch 2.x)
         opt.adjust_learning_rate(optimizer, 0.01, it, max_iter, 0.9, -1)
         loss = model(images, labels, deepsup=True)
         reduce_loss = engine.all_reduce_tensor(loss["loss"]) if ddp else loss["loss"]
@@ -263,6 +263,7 @@ def main():
             roof, extra = roofline_from_profile(recs, args.batch, step_s)
     fence()
     peak_mem = torch.cuda.max_memory_allocated() / 2**30
+    sgd_rebuilds = getattr(optimizer, "table_rebuilds", None)   # pointer-table uploads (2 = built once per group)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -305,6 +306,7 @@ def main():
                                       "CE+0.4*deepsup CE (fused upsample), SyncBN+DDP, EIC step, SGD m0.9 wd5e-4",
                           "global_batch": global_batch, "parallelism": f"dp{world}"},
                "final_loss": last, "peak_mem_GiB": peak_mem,
+               "sgd_table_rebuilds": sgd_rebuilds,
                "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone, args.channel_cfg) == (1024, 2048, "resnet101", None) else None,
                "roofline": roof, "cpu_baseline": cpu, "alt_math": alt, "detail": extra}
         print(json.dumps(out))

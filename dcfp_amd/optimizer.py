@@ -45,6 +45,7 @@ class FusedSGD(torch.optim.Optimizer):
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached[1], cached[2], cached[3]
+        self.table_rebuilds = getattr(self, "table_rebuilds", 0) + 1
         entries = (SgdEntry * len(params))()
         chunk = 0
         for i, p in enumerate(params):

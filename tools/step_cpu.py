@@ -34,7 +34,7 @@ def main():
     for it in range(6):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad()
         opt.adjust_learning_rate(optimizer, 0.01, it, 4000, 0.9, -1)
         loss = model(images, labels, deepsup=True)
         t1 = time.perf_counter()

@@ -26,7 +26,7 @@ def main():
     images, labels = bench.synthetic_batch(args.batch, H, W, 12345, device)
 
     def step(it):
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad()
         opt.adjust_learning_rate(optimizer, 0.01, it, 4000, 0.9, -1)
         loss = model(images, labels, deepsup=True)
         loss["loss"].item()

@@ -25,7 +25,7 @@ def main():
     images, labels = bench.synthetic_batch(4, 1024, 2048, 12345, device)
 
     def step(it):
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad()
         loss = model(images, labels, deepsup=True)
         loss["loss"].item()
         loss["loss"].backward()
