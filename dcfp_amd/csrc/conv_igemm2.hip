@@ -461,12 +461,14 @@ TileCfg pick_cfg(int M, long long px, int sd) {
 
 template <int TAPS>
 int launch_taps(Igemm2Params& p, int cfg, hipStream_t stream) {
-    if (p.accumulate) {   // residual-gradient fan-in: block inputs have >= 128 channels
+    if (p.accumulate) {   // residual-gradient fan-in (block inputs: >= 128 channels unless pruned)
         switch (cfg) {
+            case 0: return launch_cfg<TAPS, 1, 4, 1, 4, false, true>(p, stream);
+            case 1: return launch_cfg<TAPS, 2, 4, 1, 4, false, true>(p, stream);
             case 2: return launch_cfg<TAPS, 2, 4, 2, 2, false, true>(p, stream);
             case 3: return launch_cfg<TAPS, 2, 2, 2, 2, false, true>(p, stream);
             case 4: return launch_cfg<TAPS, 4, 4, 2, 2, false, true>(p, stream);
-            default: return DCFP_E_UNSUPPORTED;
+            default: return launch_cfg<TAPS, 2, 4, 2, 2, true, true>(p, stream);
         }
     }
     switch (cfg) {
