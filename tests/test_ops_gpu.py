@@ -247,3 +247,28 @@ def test_gsrl_loss_vs_reference_golden(cuda, tag):
     assert abs(loss.item() - float(g[f"loss:{tag}"])) < 2e-6 * max(1.0, abs(float(g[f"loss:{tag}"])))
     assert rel_err(z0.grad, torch.from_numpy(g[f"g0:{tag}"])) < 2e-5
     assert rel_err(z1.grad, torch.from_numpy(g[f"g1:{tag}"])) < 2e-5
+
+
+@pytest.mark.parametrize("world,C", [(1, 64), (3, 257), (8, 19)])
+def test_syncbn_combine_kernel(cuda, world, C):
+    """Pooled SyncBatchNorm statistics from the all-gathered per-rank rows (mean, var, count) —
+    the device-side half of ops.sync_bn_stats — against the parallel-variance formula in fp64."""
+    import ctypes as C_
+    from dcfp_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    means = torch.randn(world, C, generator=g)
+    vars_ = torch.rand(world, C, generator=g) + 0.1
+    counts = torch.tensor([float(1000 + 37 * r) for r in range(world)])
+    rows = torch.cat([means, vars_, counts[:, None]], dim=1).contiguous()
+    tot = counts.double().sum()
+    gm = (means.double() * counts.double()[:, None]).sum(0) / tot
+    gv = ((vars_.double() + (means.double() - gm) ** 2) * counts.double()[:, None]).sum(0) / tot
+    dev_rows = rows.to(cuda)
+    out = torch.empty(2 * C + 1, device=cuda)
+    rc = _lib.lib().dcfp_syncbn_combine_f32(ops._p(dev_rows), world, C, ops._p(out), ops._p(out[C:]),
+                                            ops._p(out[2 * C:]), ops._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert max_err(out[:C], gm) < 1e-6
+    assert max_err(out[C:2 * C], gv) < 1e-6
+    assert abs(out[2 * C].item() - tot.item()) < 1e-3
