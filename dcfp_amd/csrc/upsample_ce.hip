@@ -239,6 +239,75 @@ upsample_ce_bwd_kernel(const float* __restrict__ logits, const long long* __rest
     }
 }
 
+// Same gradient, thread <-> one low-resolution pixel (n,i,j) with ALL classes in registers (CT of
+// them, compile-time): the per-destination-pixel work that does not depend on the class — the two
+// interpolation stencils, the tap weights, label, LSE — is done once instead of once per class
+// (3.0 -> ~1 ms per head at 19 classes).  The logit interpolation keeps the forward's expression.
+template <bool ALIGN, int CT>
+__global__ void __launch_bounds__(kThreads)
+upsample_ce_bwd_classes_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                               const uint8_t* __restrict__ keep, int ignore_index, int N, int h, int w,
+                               int H, int W, float sh, float sw, const float* __restrict__ lse,
+                               const float* __restrict__ grad_scale, float* __restrict__ dlogits) {
+    // four lanes share one low-resolution pixel (destination rows Y = ylo + part, +4, ...) and
+    // combine their partial sums with two butterfly shuffles: 4x the waves for latency hiding
+    const long long total = (long long)N * h * w * 4;
+    const long long plane = (long long)h * w;
+    const float gs = grad_scale[0];
+    for (long long idx4 = (long long)blockIdx.x * kThreads + threadIdx.x; idx4 < total;
+         idx4 += (long long)gridDim.x * kThreads) {
+        const int part = (int)(idx4 & 3);
+        const long long idx = idx4 >> 2;
+        const int j = (int)(idx % w);
+        const long long t = idx / w;
+        const int i = (int)(t % h);
+        const int n = (int)(t / h);
+        const float* base = logits + (long long)n * CT * plane;
+        const long long* lab = labels + (long long)n * H * W;
+        const float* ls = lse + (long long)n * H * W;
+        const uint8_t* kp = keep ? keep + (long long)n * H * W : nullptr;
+        int ylo, yhi, xlo, xhi;
+        dst_range<ALIGN>(i, sh, H, ylo, yhi);
+        dst_range<ALIGN>(j, sw, W, xlo, xhi);
+        float acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+        for (int Y = ylo + part; Y <= yhi; Y += 4) {
+            const Lerp Lh = lerp_of<ALIGN>(Y, sh, h);
+            const float wy = tap_weight(Lh, i);
+            if (wy == 0.f) continue;
+            for (int X = xlo; X <= xhi; ++X) {
+                const Lerp Lw = lerp_of<ALIGN>(X, sw, w);
+                const float wgt = wy * tap_weight(Lw, j);
+                if (wgt == 0.f) continue;
+                const long long q = (long long)Y * W + X;
+                const long long label = lab[q];
+                if (label == ignore_index || (kp && !kp[q])) continue;
+                const int o00 = Lh.i0 * w + Lw.i0, o01 = Lh.i0 * w + Lw.i1;
+                const int o10 = Lh.i1 * w + Lw.i0, o11 = Lh.i1 * w + Lw.i1;
+                const float lq = ls[q];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const float* p = base + c * plane;
+                    const float z = Lh.l0 * (Lw.l0 * p[o00] + Lw.l1 * p[o01]) +
+                                    Lh.l1 * (Lw.l0 * p[o10] + Lw.l1 * p[o11]);
+                    acc[c] += wgt * (expf(z - lq) - (label == c ? 1.f : 0.f));
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {   // fixed combination order: (p0+p1)+(p2+p3)
+            acc[c] += __shfl_xor(acc[c], 1, 64);
+            acc[c] += __shfl_xor(acc[c], 2, 64);
+        }
+        if (part == 0) {
+            float* o = dlogits + (long long)n * CT * plane + (long long)i * w + j;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) o[c * plane] = acc[c] * gs;
+        }
+    }
+}
+
 // OHEM threshold search input (loss/ohem.py:20-33): the reference zooms the full-resolution
 // softmax to 1/factor with scipy.ndimage.zoom(order=1) and the labels with order=0, then
 // gathers the zoomed probability of the zoomed label.  Per zoomed position that is a bilinear
@@ -596,6 +665,19 @@ extern "C" int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labe
     const long long* lab = reinterpret_cast<const long long*>(labels);
     long long blocks = (total + kThreads - 1) / kThreads;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    if (C == 19) {   // Cityscapes (datasets/CSdatasets.py:13): class-batched variant
+        const long long tot2 = (long long)N * h * w * 4;   // 4 lanes per low-resolution pixel
+        const unsigned b2 = (unsigned)((tot2 + kThreads - 1) / kThreads);
+        if (align_corners)
+            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<true, 19>), dim3(b2), dim3(kThreads), 0,
+                               dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw,
+                               lse, grad_scale, dlogits);
+        else
+            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<false, 19>), dim3(b2), dim3(kThreads), 0,
+                               dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw,
+                               lse, grad_scale, dlogits);
+        DCFP_RETURN_LAUNCH();
+    }
     if (align_corners)
         hipLaunchKernelGGL(upsample_ce_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
                            dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, C, h, w, H, W,
