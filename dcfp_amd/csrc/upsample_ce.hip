@@ -248,12 +248,13 @@ __global__ void __launch_bounds__(kThreads)
 upsample_ce_bwd_classes_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                const uint8_t* __restrict__ keep, int ignore_index, int N, int h, int w,
                                int H, int W, float sh, float sw, const float* __restrict__ lse,
-                               const float* __restrict__ grad_scale, float* __restrict__ dlogits) {
+                               const float* __restrict__ grad_scale, float* __restrict__ dlogits,
+                               const float* __restrict__ pix_weight /* GSRL weights, nullable */,
+                               int scale_per_image /* grad_scale[n] instead of grad_scale[0] */) {
     // four lanes share one low-resolution pixel (destination rows Y = ylo + part, +4, ...) and
     // combine their partial sums with two butterfly shuffles: 4x the waves for latency hiding
     const long long total = (long long)N * h * w * 4;
     const long long plane = (long long)h * w;
-    const float gs = grad_scale[0];
     for (long long idx4 = (long long)blockIdx.x * kThreads + threadIdx.x; idx4 < total;
          idx4 += (long long)gridDim.x * kThreads) {
         const int part = (int)(idx4 & 3);
@@ -266,6 +267,8 @@ upsample_ce_bwd_classes_kernel(const float* __restrict__ logits, const long long
         const long long* lab = labels + (long long)n * H * W;
         const float* ls = lse + (long long)n * H * W;
         const uint8_t* kp = keep ? keep + (long long)n * H * W : nullptr;
+        const float* wp = pix_weight ? pix_weight + (long long)n * H * W : nullptr;
+        const float gs = grad_scale[scale_per_image ? n : 0];
         int ylo, yhi, xlo, xhi;
         dst_range<ALIGN>(i, sh, H, ylo, yhi);
         dst_range<ALIGN>(j, sw, W, xlo, xhi);
@@ -278,11 +281,16 @@ upsample_ce_bwd_classes_kernel(const float* __restrict__ logits, const long long
             if (wy == 0.f) continue;
             for (int X = xlo; X <= xhi; ++X) {
                 const Lerp Lw = lerp_of<ALIGN>(X, sw, w);
-                const float wgt = wy * tap_weight(Lw, j);
+                float wgt = wy * tap_weight(Lw, j);
                 if (wgt == 0.f) continue;
                 const long long q = (long long)Y * W + X;
                 const long long label = lab[q];
                 if (label == ignore_index || (kp && !kp[q])) continue;
+                if (wp) {
+                    const float pwq = wp[q];
+                    if (pwq == 0.f) continue;
+                    wgt *= pwq;
+                }
                 const int o00 = Lh.i0 * w + Lw.i0, o01 = Lh.i0 * w + Lw.i1;
                 const int o10 = Lh.i1 * w + Lw.i0, o11 = Lh.i1 * w + Lw.i1;
                 const float lq = ls[q];
@@ -671,11 +679,11 @@ extern "C" int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labe
         if (align_corners)
             hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<true, 19>), dim3(b2), dim3(kThreads), 0,
                                dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw,
-                               lse, grad_scale, dlogits);
+                               lse, grad_scale, dlogits, nullptr, 0);
         else
             hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<false, 19>), dim3(b2), dim3(kThreads), 0,
                                dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw,
-                               lse, grad_scale, dlogits);
+                               lse, grad_scale, dlogits, nullptr, 0);
         DCFP_RETURN_LAUNCH();
     }
     if (align_corners)
@@ -777,6 +785,19 @@ extern "C" int dcfp_upsample_wce_bwd_f32(const float* logits, const int64_t* lab
     const long long* lab = reinterpret_cast<const long long*>(labels);
     long long blocks = (total + kThreads - 1) / kThreads;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    if (C == 19) {   // class-batched variant (see upsample_ce_bwd_classes_kernel)
+        const long long tot2 = (long long)N * h * w * 4;
+        const unsigned b2 = (unsigned)((tot2 + kThreads - 1) / kThreads);
+        if (align_corners)
+            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<true, 19>), dim3(b2), dim3(kThreads), 0,
+                               dcfp_s(stream), logits, lab, nullptr, ignore_index, N, h, w, H, W, sh, sw, lse,
+                               grad_scale_per_image, dlogits, pix_weight, 1);
+        else
+            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<false, 19>), dim3(b2), dim3(kThreads), 0,
+                               dcfp_s(stream), logits, lab, nullptr, ignore_index, N, h, w, H, W, sh, sw, lse,
+                               grad_scale_per_image, dlogits, pix_weight, 1);
+        DCFP_RETURN_LAUNCH();
+    }
     if (align_corners)
         hipLaunchKernelGGL(upsample_wce_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
                            dcfp_s(stream), logits, lab, pix_weight, ignore_index, N, C, h, w, H, W, sh, sw,
