@@ -55,6 +55,9 @@ SIGNATURES = {
                                     _P, _Z, _P]),
     "dcfp_bn_update_running_f32": (_I, [_P, _P, _I, _F, _F, _P, _P, _P, _P]),
     "dcfp_syncbn_combine_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "dcfp_conv2d_fwd_stat_slots": (_L, [_D, _P, _L]),
+    "dcfp_conv2d_fwd_stats_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _P, _Z, _P]),
+    "dcfp_bn_stats_from_partials_f32": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "dcfp_bn_bwd_apply_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _P, _P, _F, _P, _I, _P, _P,
                                    _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -245,6 +245,41 @@ __global__ void syncbn_combine_kernel(const float* __restrict__ allv, int world,
     if (c == 0) total[0] = (float)tot;
 }
 
+// Batch statistics from the conv epilogue's partials: part[s][c] = (mean_s, M2_s) of `cnt` values
+// each.  One block per channel; Chan's parallel combination in fp64, fixed order:
+//   mean = avg(mean_s),  var = (sum M2_s + cnt * sum (mean_s - mean)^2) / (S * cnt)   (biased)
+__global__ void __launch_bounds__(kThreads)
+bn_stats_from_partials_kernel(const float* __restrict__ part, long long S, int cnt, int C,
+                              float* __restrict__ mean, float* __restrict__ var) {
+    __shared__ double red[kThreads];
+    const int c = blockIdx.x;
+    double a = 0.0;
+    for (long long s = threadIdx.x; s < S; s += kThreads) a += (double)part[(s * C + c) * 2];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double mu = red[0] / (double)S;
+    __syncthreads();
+    double b = 0.0;
+    for (long long s = threadIdx.x; s < S; s += kThreads) {
+        const double d = (double)part[(s * C + c) * 2] - mu;
+        b += (double)part[(s * C + c) * 2 + 1] + (double)cnt * d * d;
+    }
+    red[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mean[c] = (float)mu;
+        var[c] = (float)(red[0] / ((double)S * (double)cnt));
+    }
+}
+
 // running = (1-m)*running + m*stat, variance unbiased by count/(count-1) (nn.BatchNorm2d training)
 __global__ void bn_running_kernel(int C, const float* __restrict__ mean, const float* __restrict__ var,
                                   float momentum, float count, const float* __restrict__ count_dev,
@@ -458,5 +493,13 @@ extern "C" int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, 
     if (!gathered || !mean || !var || !total_count || world <= 0 || C <= 0) return DCFP_E_BADDESC;
     hipLaunchKernelGGL(syncbn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream),
                        gathered, world, C, mean, var, total_count);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t slots, int slot_count, int C,
+                                               float* mean, float* var, dcfp_stream_t stream) {
+    if (!partials || !mean || !var || slots <= 0 || slot_count <= 0 || C <= 0) return DCFP_E_BADDESC;
+    hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((unsigned)C), dim3(kThreads), 0, dcfp_s(stream),
+                       partials, (long long)slots, slot_count, C, mean, var);
     DCFP_RETURN_LAUNCH();
 }

@@ -330,7 +330,8 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale = nullptr, const float* shift = nullptr,
-                    const float* residual = nullptr, int relu = 0);
+                    const float* residual = nullptr, int relu = 0, float* stat_part = nullptr);
+long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 
 // DCFP_IGEMM_V1=1 keeps the first-generation kernel (A/B comparisons in one process).
 static bool use_v1() {
@@ -417,6 +418,31 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     p.wgt_bytes = d->Cout * d->Cin * T * 4;
     p.vec_store = (p.P % 4 == 0) && (p.out_nstride % 4 == 0) && dcfp_aligned16(y);
     return T == 1 ? launch_taps<1>(p, dcfp_s(stream)) : launch_taps<9>(p, dcfp_s(stream));
+}
+
+// Forward conv that also emits BatchNorm batch-statistics partials of its output (see
+// dcfp_bn_stats_from_partials_f32).  slots == 0: this shape / math mode has no fused statistics.
+extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride) {
+    if (check_desc(d) != DCFP_OK || use_v1()) return 0;
+    if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1)) return 0;
+    return dcfp_igemm2_stat_slots(d->Cout, d->Hout * d->Wout, d->N,
+                                  y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, y);
+}
+
+extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
+                                              float* y, int64_t y_nstride, float* stat_partials,
+                                              void* workspace, size_t workspace_bytes,
+                                              dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y || !stat_partials) return DCFP_E_BADDESC;
+    if (dcfp_conv2d_fwd_stat_slots(d, y, y_nstride) <= 0) return DCFP_E_UNSUPPORTED;
+    const int T = d->KH * d->KW;
+    return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
+                           y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
+                           d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
+                           d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr,
+                           nullptr, 0, stat_partials);
 }
 
 extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy,

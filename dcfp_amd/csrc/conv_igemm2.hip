@@ -39,6 +39,7 @@ struct Igemm2Params {
     int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
     int sn, sd, off0, offstep;
     int accumulate, vec_store;
+    float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
 };
 
 // Wp[t][c][m] = W[m*sAm + c*sAc + t]  (zero for c >= Ck or m >= M)
@@ -87,6 +88,17 @@ template <>
 struct Frag<1> {
     static __device__ __forceinline__ void ld(const float* p, float (&f)[1]) { f[0] = p[0]; }
 };
+
+// value of lane (l ^ MASK) within each 32-lane half (ds_swizzle bit-mask mode: and 0x1f, xor MASK)
+__device__ __forceinline__ float half_xor(float v, int mask) {
+    switch (mask) {
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (1 << 10) | 0x1f));
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (2 << 10) | 0x1f));
+        case 4: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (4 << 10) | 0x1f));
+        case 8: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (8 << 10) | 0x1f));
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1f));
+    }
+}
 
 // ACC: dx += result (gradient fan-in of a residual branch); only the epilogue differs.
 template <int TAPS, int TM, int TN, int WM, int WN, bool SD, bool ACC, int KB = 16>
@@ -313,6 +325,49 @@ igemm2_kernel(const Igemm2Params p) {
             unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
             asm volatile("" : "+v"(voff));
             const unsigned P4 = (unsigned)p.P * 4u;
+            if constexpr (!ACC) {
+                // BatchNorm batch statistics of the conv output, for free: each wave half holds 128
+                // pixels of 16 x TM rows, so it emits (mean, sum of squared deviations) of those 128
+                // values per row - Welford-style partials that dcfp_bn_stats_from_partials_f32
+                // merges in a fixed order in fp64 (no pivot needed, no second pass over y).
+                if (p.stat_part) {
+                    float* sp = p.stat_part +
+                                ((long long)(nt * WN + wn) * p.M + m0 + wm * (TM * 32) + TM * 4 * lhi) * 2;
+                    static_for<0, TM>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        // the 16 rows of one MFMA row tile advance through the butterfly together:
+                        // 16 independent cross-lane exchanges in flight per step instead of a
+                        // serial chain of ten per row
+                        float sm[16], q[16];
+                        static_for<0, 16>([&](auto r_) {
+                            constexpr int r = decltype(r_)::value;
+                            sm[r] = (acc[i][0][r] + acc[i][1][r]) + (acc[i][2][r] + acc[i][3][r]);
+                        });
+                        static_for<0, 5>([&](auto st_) {
+                            constexpr int mask = 1 << decltype(st_)::value;
+                            static_for<0, 16>([&](auto r_) { constexpr int r = decltype(r_)::value; sm[r] += half_xor(sm[r], mask); });
+                        });
+                        static_for<0, 16>([&](auto r_) {
+                            constexpr int r = decltype(r_)::value;
+                            sm[r] *= (1.0f / 128.0f);
+                            const float d0 = acc[i][0][r] - sm[r], d1 = acc[i][1][r] - sm[r];
+                            const float d2 = acc[i][2][r] - sm[r], d3 = acc[i][3][r] - sm[r];
+                            q[r] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                        });
+                        static_for<0, 5>([&](auto st_) {
+                            constexpr int mask = 1 << decltype(st_)::value;
+                            static_for<0, 16>([&](auto r_) { constexpr int r = decltype(r_)::value; q[r] += half_xor(q[r], mask); });
+                        });
+                        if (l31 == 0) {
+                            static_for<0, 16>([&](auto r_) {
+                                constexpr int r = decltype(r_)::value;
+                                constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                                sp[row * 2] = sm[r]; sp[row * 2 + 1] = q[r];
+                            });
+                        }
+                    });
+                }
+            }
             static_for<0, TM>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 f32x4 old[16];
@@ -495,6 +550,15 @@ size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
 
 int dcfp_igemm2_cfg_id(int M, long long px, int sd) { return pick_cfg(M, px, sd).id; }
 
+// Number of (mean, M2) partial rows per channel the forward kernel can emit for this shape (each
+// over 128 pixels), or 0 when some tile is not interior / the tile shape has no fused statistics.
+long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out) {
+    const TileCfg c = pick_cfg(M, (long long)N * P, 1);
+    if (c.id != 0 && c.id != 1 && c.id != 2 && c.id != 4) return 0;          // TN == 4 tiles only
+    if (M % c.bm != 0 || P % c.bn != 0 || P % 4 != 0 || out_nstride % 4 != 0 || !dcfp_aligned16(out)) return 0;
+    return (long long)N * (P / c.bn) * (c.bn / 128);
+}
+
 const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
     switch (pick_cfg(M, px, sd).id) {
         case 0: return "1,4,1,4,0";
@@ -511,10 +575,12 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                    const float* scale, const float* shift, const float* residual, int relu) {
+                    const float* scale, const float* shift, const float* residual, int relu,
+                    float* stat_part) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
+    p.stat_part = stat_part;
     p.in = in; p.bias = bias; p.out = out;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;

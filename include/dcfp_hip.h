@@ -119,6 +119,18 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                            int relu, int N, int C, int HW,
                            float* sum_dy, float* sum_dy_xmu, float* dgamma /* nullable: sum_dy_xmu*istd */,
                            void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
+/* Conv forward that also emits the BatchNorm batch statistics of its OUTPUT as partials
+ * (resnet.py:25-33: every conv is followed by a BatchNorm that needs mean/var over N,H,W):
+ * stat_partials[slot][Cout][2] = (mean, sum of squared deviations) over 128 output pixels each.
+ * dcfp_conv2d_fwd_stat_slots() gives the slot count for a shape (0: not available - tiles off
+ * the channel/pixel grid, bias, or DCFP_CONV_MATH=bf16x3 - use dcfp_bn_stats_f32 then);
+ * dcfp_bn_stats_from_partials_f32 merges them in a fixed order in fp64 (biased variance). */
+int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride);
+int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y,
+                                   int64_t y_nstride, float* stat_partials, void* workspace,
+                                   size_t workspace_bytes, dcfp_stream_t stream);
+int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t slots, int slot_count, int C,
+                                    float* mean, float* var, dcfp_stream_t stream);
 /* SyncBatchNorm (engine.py:65) forward exchange, device side: `gathered` = world rows of
  * (mean[C], var[C], count) as all-gathered from the ranks -> pooled mean, biased variance over all
  * ranks' pixels and the total count (one float, stays on the device). */

@@ -272,3 +272,23 @@ def test_syncbn_combine_kernel(cuda, world, C):
     assert max_err(out[:C], gm) < 1e-6
     assert max_err(out[C:2 * C], gv) < 1e-6
     assert abs(out[2 * C].item() - tot.item()) < 1e-3
+
+
+@pytest.mark.parametrize("Cout,k", [(256, 1), (128, 3), (64, 1), (512, 1)])
+def test_conv_fused_bn_stats(cuda, Cout, k):
+    """BatchNorm batch statistics emitted by the conv epilogue (Welford partials over 128-pixel
+    runs, merged in fp64) against the statistics of the conv output itself and bn_stats."""
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, Cin, H, W = 2, 24, 128, 256
+    x = (torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.7).to(cuda)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k) + 0.05).to(cuda)
+    y, stats = ops.conv2d_fwd(x, w, None, 1, k // 2, 1, want_stats=True)
+    assert stats is not None, "shape should route to a tile with fused statistics"
+    y_plain = ops.conv2d_fwd(x, w, None, 1, k // 2, 1)
+    assert torch.equal(y, y_plain)
+    m64 = y.double().mean(dim=(0, 2, 3)); v64 = y.double().var(dim=(0, 2, 3), unbiased=False)
+    assert max_err(stats[0], m64) < 2e-6 * max(1.0, m64.abs().max().item())
+    assert ((stats[1].double().cpu() - v64.cpu()).abs() / v64.cpu()).max().item() < 2e-6
+    m2, v2 = ops.bn_stats(y)
+    assert max_err(stats[0], m2) < 2e-6 and ((stats[1] - v2).abs() / v2).max().item() < 2e-6
