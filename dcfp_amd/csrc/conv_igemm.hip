@@ -344,7 +344,9 @@ size_t dcfp_igemm3_workspace_bytes(int T, int M, int Ck);
 int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
                     const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
                     int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
-                    void* workspace, size_t workspace_bytes, hipStream_t stream);
+                    void* workspace, size_t workspace_bytes, hipStream_t stream,
+                    const float* scale = nullptr, const float* shift = nullptr,
+                    const float* residual = nullptr, int relu = 0);
 int dcfp_igemm2_cfg_id(int M, long long px, int sd);
 static bool math_bf16x3() {
     static const bool v = [] { const char* e = getenv("DCFP_CONV_MATH"); return e && !strcmp(e, "bf16x3"); }();
@@ -488,6 +490,11 @@ extern "C" int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float
     if (!x || !w || !y || !scale || !shift) return DCFP_E_BADDESC;
     if (use_v1()) return DCFP_E_UNSUPPORTED;
     const int T = d->KH * d->KW;
+    if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))   // opt-in bf16x3 inference
+        return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
+                               (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,
+                               d->Hout, d->Wout, -d->pad, d->dil, 0, workspace, workspace_bytes,
+                               dcfp_s(stream), scale, shift, residual, relu ? 1 : 0);
     return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
                            (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,
                            d->Hout, d->Wout, d->stride, 1, -d->pad, d->dil, 0, workspace, workspace_bytes,

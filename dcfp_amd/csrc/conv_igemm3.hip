@@ -52,6 +52,10 @@ struct Igemm3Params {
     int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
     int off0, offstep;
     int accumulate;
+    const float* scale;      // inference epilogue (EPI == 2): y = act(acc*scale[m] + shift[m] (+ residual))
+    const float* shift;
+    const float* residual;   // same layout as out, nullable
+    int relu;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -125,9 +129,11 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* lo, const __bf16* hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// ACC: dx += result (gradient fan-in of a residual branch); only the epilogue differs.
-template <int TAPS, bool ACC>
+// EPI selects the epilogue only: 0 plain store, 1 dx += result (gradient fan-in of a residual
+// branch), 2 inference: folded eval-mode BatchNorm (+residual) (+ReLU) as in conv_igemm2.hip.
+template <int TAPS, int EPI>
 __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
+    constexpr bool ACC = EPI == 1;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_i3[];
     __bf16* As = smem_i3;                // [2][3][BM][APITCH]
     __bf16* Bs = smem_i3 + 2 * ABUF;     // [2][3][BK][BPITCH]
@@ -412,6 +418,9 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
         unsigned voff = (unsigned)((wm * 128 + 4 * lhi) * p.P + wn * 128 + l31) * 4u;
         asm volatile("" : "+v"(voff));
         const unsigned P4 = (unsigned)p.P * 4u;
+        const float* r_base = (EPI == 2 && p.residual) ? p.residual + (long long)img * p.out_nstride : o_img;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(r_base) + (long long)m0 * p.P + p0, 0, kMaxRecords, 0x00020000);
         static_for<0, 4>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             static_for<0, 2>([&](auto hf_) {       // 8 rows x 4 column tiles per batch
@@ -432,10 +441,22 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
                 static_for<0, 8>([&](auto rr_) {
                     constexpr int r = 8 * hf + decltype(rr_)::value;
                     constexpr int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    float sc = 1.f, sf = 0.f;
+                    if constexpr (EPI == 2) {
+                        const int m = m0 + wm * 128 + 4 * lhi + row;
+                        sc = p.scale[m]; sf = p.shift[m];
+                    }
                     static_for<0, 4>([&](auto j_) {
                         constexpr int j = decltype(j_)::value;
                         float v = acc[i][j][r];
                         if constexpr (ACC) v += old[r - 8 * hf][j];
+                        if constexpr (EPI == 2) {
+                            v = fmaf(v, sc, sf);
+                            if (p.residual)
+                                v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                    r_rsrc, voff + 128u * j, (unsigned)row * P4, 0));
+                            if (p.relu) v = v > 0.f ? v : 0.f;
+                        }
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc,
                                                               voff + 128u * j, (unsigned)row * P4, 0);
                     });
@@ -455,11 +476,18 @@ __global__ void __launch_bounds__(256) igemm3_kernel(const Igemm3Params p) {
             const int m = m0 + wm * 128 + i * 32 + row;
             if (m >= p.M) continue;
             float* dst = o_img + (long long)m * p.P + pix;
+            float sc = 1.f, sf = 0.f;
+            if constexpr (EPI == 2) { sc = p.scale[m]; sf = p.shift[m]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (pix + 32 * j < p.P) {
                     float v = acc[i][j][r];
                     if constexpr (ACC) v += dst[32 * j];
+                    if constexpr (EPI == 2) {
+                        v = fmaf(v, sc, sf);
+                        if (p.residual) v += p.residual[(dst - p.out) + 32 * j];
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                    }
                     dst[32 * j] = v;
                 }
             }
@@ -480,7 +508,8 @@ size_t dcfp_igemm3_workspace_bytes(int T, int M, int Ck) {
 int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
                     const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
                     int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
-                    void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                    void* workspace, size_t workspace_bytes, hipStream_t stream, const float* scale,
+                    const float* shift, const float* residual, int relu) {
     Igemm3Params p;
     if (bias) return DCFP_E_UNSUPPORTED;   // callers route bias convs to the fp32 kernel
     p.in = in; p.out = out;
@@ -492,6 +521,8 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
     p.tiles_m = p.Mpad / BM;
     p.off0 = off0; p.offstep = offstep;
     p.accumulate = accumulate;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
+    if (scale && (accumulate || !shift)) return DCFP_E_BADDESC;
     const size_t need = dcfp_igemm3_workspace_bytes(T, M, Ck);
     if (!workspace || workspace_bytes < need || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
     if ((long long)Ck * Hi * Wi * 4 > 0x7fffffffLL || need > 0x7fffffffULL) return DCFP_E_UNSUPPORTED;
@@ -516,8 +547,9 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
         return hipSuccess;
     };
     hipError_t e;
-    if (T == 1) e = accumulate ? launch(igemm3_kernel<1, true>) : launch(igemm3_kernel<1, false>);
-    else        e = accumulate ? launch(igemm3_kernel<9, true>) : launch(igemm3_kernel<9, false>);
+    const int epi = scale ? 2 : accumulate ? 1 : 0;
+    if (T == 1) e = epi == 2 ? launch(igemm3_kernel<1, 2>) : epi == 1 ? launch(igemm3_kernel<1, 1>) : launch(igemm3_kernel<1, 0>);
+    else        e = epi == 2 ? launch(igemm3_kernel<9, 2>) : epi == 1 ? launch(igemm3_kernel<9, 1>) : launch(igemm3_kernel<9, 0>);
     if (e != hipSuccess) return (int)e;
     DCFP_RETURN_LAUNCH();
 }

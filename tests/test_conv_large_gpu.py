@@ -52,6 +52,11 @@ def _child():
         dxa = seed.to(dev)
         ops.conv2d_dgrad(dyg, wg, tuple(x.shape), 1, p, d, out=dxa, accumulate=True)
         dw = ops.conv2d_wgrad(dyg, xg, tuple(w.shape), 1, p, d)[0]
+        # inference epilogue: folded eval-mode BatchNorm + residual + ReLU in the conv kernel
+        sc = torch.rand(Cout, generator=g) + 0.5
+        sh = torch.randn(Cout, generator=g) * 0.3
+        resid = torch.randn(y.shape, generator=g)
+        yf = ops.conv2d_fused_infer(xg, wg, sc.to(dev), sh.to(dev), 1, p, d, resid.to(dev), True)
         torch.cuda.synchronize()
         # fp64 reference on a slice of output channels (forward / wgrad) or input channels (dgrad)
         mo = slice(Cout - 40, Cout)                        # includes the ragged last M tile
@@ -60,9 +65,11 @@ def _child():
         x64 = x[:, ci].double().requires_grad_(True)
         w64 = w[:, ci].double().requires_grad_(True)
         F.conv2d(x64, w64, None, 1, p, d).backward(dy.double())
+        yf64 = torch.relu(y64 * sc[mo].double()[None, :, None, None] + sh[mo].double()[None, :, None, None]
+                          + resid[:, mo].double())
         out.append({
             "case": [N, Cin, H, W, Cout, k, p, d], "kernels": names,
-            "fwd": rel(y[:, mo], y64), "dgrad": rel(dx[:, ci], x64.grad),
+            "fwd": rel(y[:, mo], y64), "fused_infer": rel(yf[:, mo], yf64), "dgrad": rel(dx[:, ci], x64.grad),
             "dgrad_acc": rel(dxa[:, ci], x64.grad + seed[:, ci].double()),
             "wgrad": rel(dw[:, ci], w64.grad),
         })
@@ -88,6 +95,7 @@ def test_large_conv_parity(cuda, mode):
         K = Cin * k * k
         tol = 3e-6 * max(1.0, math.sqrt(K) / 8)            # as test_conv_fwd_dgrad_wgrad
         assert rec["fwd"] < tol, rec
+        assert rec["fused_infer"] < tol, rec
         assert rec["dgrad"] < max(tol, 1e-5), rec
         assert rec["dgrad_acc"] < max(tol, 1e-5), rec
         assert rec["wgrad"] < 2e-5, rec

@@ -34,7 +34,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"inference: {a.batch * a.iters / dt:.2f} images/s ({dt / a.iters * 1e3:.1f} ms per batch of {a.batch}) "
-          f"DeepLabv3-{a.backbone} {h}x{w} fp32")
+          f"DeepLabv3-{a.backbone} {h}x{w} fp32" + (" (conv math: bf16x3 split)" if os.environ.get("DCFP_CONV_MATH") == "bf16x3" else ""))
 
 
 if __name__ == "__main__":
