@@ -47,198 +47,6 @@ struct WgradParams {
 constexpr unsigned kOob = 0x80000000u;      // > any record count: buffer loads return 0
 constexpr unsigned kMaxRecords = 0x7ffffffcu;
 
-template <int TAPS, int TM, int TN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(const WgradParams p) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
-    constexpr int ROWS = NT / 4;  // rows staged per pass (4 threads x 4 pixels per row)
-    constexpr int PA = BM / ROWS, PB = BN / ROWS;
-    static_assert(PA >= 1 && PB >= 1 && PA * ROWS == BM && PB * ROWS == BN, "loader shape");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [2][BM][BKP]
-    float* Bs = smem + 2 * BM * BKP;      // [2][BN][BKP]
-
-    const int tiles = p.tiles_m * p.tiles_n;
-    const int split = blockIdx.x / tiles;
-    const int tile = blockIdx.x - split * tiles;
-    const int mt = tile / p.tiles_n, ntile = tile - mt * p.tiles_n;
-    const int m0 = mt * BM, n0 = ntile * BN;
-    const int kbeg = split * p.kchunk;   // Kpix < 2^31 is checked on the host
-    int kend = kbeg + p.kchunk;
-    if (kend > p.Kpix || kend < kbeg) kend = p.Kpix;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid - wm * WN;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int kx = tid & 3, rrow = tid >> 2;
-
-    // Buffer descriptors based at the first image this split touches (block-uniform);
-    // invalid lanes use offset kOob and read 0 without branching.
-    const int img0 = kbeg / p.P;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.dy + (long long)img0 * p.dy_nstride), 0, kMaxRecords, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (long long)img0 * p.x_nstride), 0, kMaxRecords, 0x00020000);
-    const int dyn = (int)p.dy_nstride, xn = (int)p.x_nstride;
-
-    // ---- per-thread rows (fixed over the K loop)
-    int a_off[PA];
-    bool a_ok[PA];
-#pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int m = m0 + rrow + ROWS * j;
-        a_ok[j] = m < p.M;
-        a_off[j] = m * p.P;
-    }
-    int b_coff[PB], b_dh[PB], b_dw[PB];
-    bool b_ok[PB];
-    const int HW = p.H * p.W;
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        const int nn = n0 + rrow + ROWS * j;
-        b_ok[j] = nn < p.Nn;
-        const int ci = nn / TAPS;
-        const int t = nn - ci * TAPS;
-        const int kh = (TAPS == 9) ? t / 3 : 0;
-        const int kw = (TAPS == 9) ? t - kh * 3 : 0;
-        b_coff[j] = ci * HW;
-        b_dh[j] = kh * p.dil - p.pad;
-        b_dw[j] = kw * p.dil - p.pad;
-    }
-
-    float areg[PA][4], breg[PB][4];
-
-    auto load_tile = [&](int kbase) {
-        // coordinates of this thread's 4 pixels
-        int img[4], pp[4], ih[4], iw[4];
-        bool qv[4];
-        const int q0 = kbase + 4 * kx;
-        if (p.quad_ok) {
-            const int imabs = q0 / p.P;
-            const int pq = q0 - imabs * p.P;
-            const int im = imabs - img0;
-            const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                img[e] = im; pp[e] = pq + e;
-                ih[e] = oh * p.stride; iw[e] = (ow + e) * p.stride;
-                qv[e] = (q0 + e) < kend;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int q = q0 + e;
-                qv[e] = q < kend;
-                const int imabs = q / p.P;
-                const int pq = q - imabs * p.P;
-                const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
-                img[e] = imabs - img0; pp[e] = pq;
-                ih[e] = oh * p.stride; iw[e] = ow * p.stride;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PA; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned off = (a_ok[j] && qv[e])
-                                         ? (unsigned)(img[e] * dyn + a_off[j] + pp[e]) * 4u : kOob;
-                areg[j][e] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off, 0, 0));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int hh = ih[e] + b_dh[j], ww = iw[e] + b_dw[j];
-                const bool ok = b_ok[j] && qv[e] && hh >= 0 && ww >= 0 && hh < p.H && ww < p.W;
-                const unsigned off = ok ? (unsigned)(img[e] * xn + b_coff[j] + hh * p.W + ww) * 4u : kOob;
-                breg[j][e] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, off, 0, 0));
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* a = As + buf * (BM * BKP);
-#pragma unroll
-        for (int j = 0; j < PA; ++j)
-            *reinterpret_cast<float4*>(a + (rrow + ROWS * j) * BKP + 4 * kx) =
-                make_float4(areg[j][0], areg[j][1], areg[j][2], areg[j][3]);
-        float* b = Bs + buf * (BN * BKP);
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-            *reinterpret_cast<float4*>(b + (rrow + ROWS * j) * BKP + 4 * kx) =
-                make_float4(breg[j][0], breg[j][1], breg[j][2], breg[j][3]);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile(kbeg);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    const int a_row = wm * (TM * 32) + l31;
-    const int b_row = wn * (TN * 32) + l31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1) < nk;
-        if (more) load_tile(kbeg + (kt + 1) * BK);
-        const float* a = As + cur * (BM * BKP) + a_row * BKP + 4 * lhi;
-        const float* b = Bs + cur * (BN * BKP) + b_row * BKP + 4 * lhi;
-#pragma unroll
-        for (int kq = 0; kq < BK / 8; ++kq) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const float4*>(a + i * 32 * BKP + kq * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const float4*>(b + j * 32 * BKP + kq * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: slab [split][M][Nn] (or dw itself when splits == 1)
-    float* o = p.out + (long long)split * p.M * p.Nn;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const int m = m0 + wm * (TM * 32) + i * 32 + row;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nn = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (nn < p.Nn) o[(long long)m * p.Nn + nn] = acc[i][j][r];
-            }
-        }
-    }
-}
-
 // compile-time loop (all indices constant expressions: register arrays stay in registers)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -251,7 +59,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((vector_size(16)));
 
-// Second-generation wgrad kernel: same tiling / LDS layout / split-K as wgrad_kernel, but
+// The wgrad kernel.  Block = WM x WN waves, wave = TM x TN MFMA tiles of 32x32; LDS holds both
+// operands K(pixel)-contiguous with a 20-float pitch; each K-step is 16 pixels (128 MFMAs on the
+// 256 x 256 tile).  What the first version's profile (matrix pipe idle ~45 %) led to:
 //  * MFMA operand fragments are double-buffered in registers (reads for the next 64 MFMAs are
 //    issued before the current 64),
 //  * the next K-step's staging (pixel coordinates tracked incrementally instead of two integer
@@ -591,11 +401,6 @@ struct Plan {
     int tiles_m, tiles_n, splits, kchunk;
 };
 
-static bool wgrad_v1() {
-    static const bool v = getenv("DCFP_WGRAD_V1") != nullptr;
-    return v;
-}
-
 Plan make_plan(const DcfpConvDesc* d) {
     Plan pl;
     const int M = d->Cout, Nn = d->Cin * d->KH * d->KW;
@@ -610,7 +415,7 @@ Plan make_plan(const DcfpConvDesc* d) {
     // workgroup per CU (512 registers/lane), so tiles*splits just above a multiple of the CU
     // count wastes most of a round (513 blocks on 256 CUs took 1.35x the time of 252).
     const int cus = num_cus();
-    const long long per_cu = pl.cfg == 2 ? 8 : (pl.cfg == 1 && !wgrad_v1()) ? 2 : 1;   // resident workgroups per CU
+    const long long per_cu = pl.cfg == 2 ? 8 : pl.cfg == 1 ? 2 : 1;   // resident workgroups per CU
     const long long slots = (long long)cus * per_cu;
     const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);   // >= 8 K-steps per split
     long long splits = 1;
@@ -666,7 +471,7 @@ template <int TAPS, int TM, int TN, int WM, int WN>
 int launch_cfg(const WgradParams& p, long long blocks, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = 64 * WM * WN;
     const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
-    auto kern = wgrad_v1() ? wgrad_kernel<TAPS, TM, TN, WM, WN> : wgrad2_kernel<TAPS, TM, TN, WM, WN>;
+    auto kern = wgrad2_kernel<TAPS, TM, TN, WM, WN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -694,7 +499,7 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : "2,2,1,1";
     if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
-    return snprintf(buf, buf_len, "%s<%d,%s>", wgrad_v1() ? "wgrad_kernel" : "wgrad2_kernel", d->KH * d->KW, args);
+    return snprintf(buf, buf_len, "wgrad2_kernel<%d,%s>", d->KH * d->KW, args);
 }
 
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
