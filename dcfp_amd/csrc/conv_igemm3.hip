@@ -18,6 +18,8 @@
 //    conflict-free on this pitch.
 // One K-step (16 channels of one tap) is 96 MFMAs x 32 cycles per wave; the staging work of the
 // next tile is cut into <= 5-instruction stages pinned behind individual MFMAs.
+// Diagnosis builds (same instruction stream minus one cost, used for the numbers in DESIGN.md §3b):
+// -DI3_DBG_NOLOADB (activation loads fetch nothing), -DI3_DBG_NOSTORE (no epilogue stores).
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>

@@ -12,6 +12,8 @@
 // per operand as [row][16 k] (pitch 24 bf16 = 48 B: conflict-free 16-byte reads).  A K-step is
 // only 96 MFMAs x 32 cycles, so each staged quad is re-loaded the moment it has been split and
 // stored: every global load gets one full K-step to land.
+// Diagnosis builds: -DW3_DBG_NOLOAD (global loads fetch nothing), -DW3_DBG_NOSTAGE (no split /
+// LDS store / reload at all) - the same instruction stream minus one cost.
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
