@@ -50,7 +50,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     const float* scale = nullptr, const float* shift = nullptr,
                     const float* residual = nullptr, int relu = 0, float* stat_part = nullptr);
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
-bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi);
+bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 
 
 // implemented in conv_igemm3.hip — EXPERIMENTAL opt-in (DCFP_CONV_MATH=bf16x3): 3-way bf16 split
@@ -100,8 +100,9 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     const int P = pass == DCFP_CONV_FWD ? d->Hout * d->Wout : d->H * d->W;
     const int HiWi = pass == DCFP_CONV_FWD ? d->H * d->W : d->Hout * d->Wout;
     const int Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
-    if (dcfp_igemm2_dma_shape(d->KH * d->KW, M, Ck, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd, d->pad, HiWi))
-        return snprintf(buf, buf_len, "igemm2_dma_kernel<1>");
+    if (dcfp_igemm2_dma_shape(d->KH * d->KW, M, Ck, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd, d->pad, HiWi,
+                              pass == DCFP_CONV_FWD ? d->Wout : d->W))
+        return snprintf(buf, buf_len, "igemm2_dma_kernel<%d>", d->KH * d->KW);
     return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW, dcfp_igemm2_cfg_args(M, px, sd));
 }
 

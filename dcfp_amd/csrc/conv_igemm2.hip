@@ -482,7 +482,12 @@ igemm2_kernel(const Igemm2Params p) {
 // (which waits vmcnt(0)) retires it.  Interior tiles only (M, P multiples of 256, Ck of 16); same-box
 // A/B against the register-staged kernel: +6...+11 % (layer4 1x1 dgrad 130 -> 142 TF = 90 % of peak).
 // DCFP_IGEMM_DMA=0 switches it off.
-template <bool ACC>
+// TAPS = 9: every K-step copies the activation rows of ONE tap, shifted by that tap's (dh, dw);
+// lanes whose pixels fall into the padding use an out-of-range offset (the copy writes zeros).  With
+// all column shifts multiples of 4 pixels (dilation 4, 8, 12, ...) a lane copies an aligned quad
+// (MIXED = false); otherwise (dilation 1, 2) the shifted taps are copied pixel by pixel with four
+// dword instructions per k-row (MIXED = true, chosen per tap).
+template <int TAPS, bool MIXED, bool ACC>
 __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -503,39 +508,92 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     const int HiWi = p.Hi * p.Wi;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // wave w copies k-rows 4w .. 4w+3 of both operands
-    unsigned a_voff[4], b_voff[4];
+    unsigned a_voff[4], b_row[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         a_voff[q] = (unsigned)((4 * wid + q) * p.Mpad) * 4u + lane * 16u;
-        b_voff[q] = (unsigned)((4 * wid + q) * HiWi) * 4u + lane * 16u;
+        b_row[q] = (unsigned)((4 * wid + q) * HiWi) * 4u;
     }
-    const int nk = p.CkP / BK;
+    // this lane's pixels: the quad 4*lane.. (16-byte copies) and pixels 64 s + lane (dword copies)
+    int q_oh, q_ow, s_oh[4], s_ow[4];
+    {
+        const int pp = p0 + 4 * lane;
+        q_oh = pp / p.Wo; q_ow = pp - q_oh * p.Wo;
+        if constexpr (MIXED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ps = p0 + 64 * e + lane;
+                s_oh[e] = ps / p.Wo; s_ow[e] = ps - s_oh[e] * p.Wo;
+            }
+        }
+    }
+    const int kpt = p.CkP / BK;
+    const int nk = TAPS * kpt;
+    unsigned boff4 = 0, boff1[4] = {0, 0, 0, 0};
+    bool tap_quads = true;            // block-uniform: this tap's column shift keeps quads aligned
+    int ld_t = 0, ld_cb = 0;          // (tap, channel block) of the tile the loader copies next
+    auto set_tap = [&](int t) {
+        const int kh = (TAPS == 9) ? t / 3 : 0;
+        const int kw = (TAPS == 9) ? t - kh * 3 : 0;
+        const int offh = p.off0 + kh * p.offstep, offw = p.off0 + kw * p.offstep;
+        tap_quads = !MIXED || (offw & 3) == 0;
+        {
+            const int hh = q_oh + offh, ww = q_ow + offw;
+            const bool ok = hh >= 0 && hh < p.Hi && ww >= 0 && ww + 3 < p.Wi;
+            boff4 = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+        }
+        if constexpr (MIXED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hh = s_oh[e] + offh, ww = s_ow[e] + offw;
+                const bool ok = hh >= 0 && hh < p.Hi && ww >= 0 && ww < p.Wi;
+                boff1[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+            }
+        }
+    };
     // The copies are issued from inline asm: through the builtin, hipcc (7.2) treats every ds_read as a
     // possible alias of the in-flight LDS-DMA and waits vmcnt(0) before the first fragment read, which
     // serialises copy and compute.  Asm loads are outside its bookkeeping, so the wait is placed by
     // hand: vmcnt(0) just before the step's (raw) barrier.
     typedef unsigned u32x4 __attribute__((vector_size(16)));
-    auto make_desc = [](const void* base) {   // raw buffer descriptor: 48-bit base, stride 0, no bound, 32-bit data
+    auto make_desc = [](const void* base, unsigned bytes) {   // raw buffer descriptor: stride 0, 32-bit data
         const unsigned long long a = (unsigned long long)base;
-        u32x4 d = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7ffffffcu, 0x00020000u};
+        u32x4 d = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
         return d;
     };
-    const u32x4 a_desc = make_desc(p.wp), b_desc = make_desc(p.in + (long long)img * p.in_nstride);
+    const u32x4 a_desc = make_desc(p.wp, 0x7ffffffcu);
+    const u32x4 b_desc = make_desc(p.in + (long long)img * p.in_nstride, (unsigned)(p.Ck * HiWi) * 4u);
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
-    auto issue = [&](int kt, int buf) {
-        const unsigned a_s = (unsigned)(kt * BK * p.Mpad + m0) * 4u;
-        const unsigned b_s = (unsigned)(kt * BK * HiWi + p0) * 4u;
+    auto issue = [&](int buf) {      // copy tile (ld_t, ld_cb) into LDS buffer `buf`, then step the loader
+        const unsigned a_s = (unsigned)((ld_t * p.CkP + ld_cb * BK) * p.Mpad + m0) * 4u;
+        const unsigned b_s = (unsigned)(ld_cb * BK * HiWi) * 4u;
         static_for<0, 4>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid + q) * BM) * 4u);
             const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BK + 4 * wid + q) * BN) * 4u);
-            const unsigned av = a_voff[q], bv = b_voff[q], as_ = a_s, bs_ = b_s;
+            const unsigned av = a_voff[q], as_ = a_s, bs_ = b_s;
             const u32x4 ad = a_desc, bd = b_desc;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
+            if (tap_quads) {
+                const unsigned bv = boff4 + b_row[q];
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
+            } else if constexpr (MIXED) {
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    const unsigned bv = boff1[e] + b_row[q];
+                    const unsigned le = lb + 256u * e, bs2 = bs_;
+                    const u32x4 bd2 = bd;      // (asm operands must be locals of the innermost lambda)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory");
+                });
+            }
         });
+        if (++ld_cb == kpt) {
+            ld_cb = 0;
+            if (++ld_t < TAPS) set_tap(ld_t);
+        }
     };
     auto retire = [&]() {   // every copy landed and every fragment read done, then the barrier
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -548,13 +606,14 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    issue(0, 0);
+    set_tap(0);
+    issue(0);
     retire();
     const int a_off = wm * (TM * 32) + TM * l31;
     const int b_off = wn * (TN * 32) + TN * l31;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        if (kt + 1 < nk) issue(cur ^ 1);
         const float* a = As + cur * (BK * BM) + a_off + lhi * BM;
         const float* b = Bs + cur * (BK * BN) + b_off + lhi * BN;
         float af[2][TM], bf[2][TN];
@@ -705,10 +764,13 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
 }
 
 // shapes the LDS-DMA kernel takes (also used for dcfp_conv2d_kernel_name)
-bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi) {
+bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo) {
     static const bool dma = [] { const char* e = getenv("DCFP_IGEMM_DMA"); return !e || atoi(e) != 0; }();   // =0: off
-    return dma && T == 1 && pick_cfg(M, px, sd).id == 4 && sn == 1 && sd == 1 && off0 == 0 && P % 256 == 0 &&
-           M % 256 == 0 && Ck % 16 == 0 && HiWi == P;
+    static const bool dma9 = [] { const char* e = getenv("DCFP_IGEMM_DMA9"); return !e || atoi(e) != 0; }();
+    if (!dma || pick_cfg(M, px, sd).id != 4 || sn != 1 || sd != 1 || P % 256 != 0 || M % 256 != 0 ||
+        Ck % 16 != 0 || HiWi != P || Wo % 4 != 0)
+        return false;
+    return T == 1 ? off0 == 0 : dma9;
 }
 
 // in: B-source tensor; w: reference-layout weights; (sAm, sAc): A strides in w
@@ -744,7 +806,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         hipLaunchKernelGGL(permute_weights_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, wp, T,
                            Ck, p.CkP, M, p.Mpad, sAm, sAc);
     }
-    if (dcfp_igemm2_dma_shape(T, M, Ck, p.P, px, sn, sd, off0, Hi * Wi) && p.vec_store && !bias && !scale &&
+    if (dcfp_igemm2_dma_shape(T, M, Ck, p.P, px, sn, sd, off0, Hi * Wi, Wo) && p.vec_store && !bias && !scale &&
         !relu && !stat_part) {
         const long long groups = ((long long)p.tiles_n_total + 7) / 8;
         const long long blocks = groups * 8 * p.tiles_m;
@@ -756,7 +818,10 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
             DCFP_RETURN_LAUNCH();
         };
-        return accumulate ? launch(igemm2_dma_kernel<true>) : launch(igemm2_dma_kernel<false>);
+        if (T == 1) return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
+        if (((off0 | offstep) & 3) == 0)
+            return accumulate ? launch(igemm2_dma_kernel<9, false, true>) : launch(igemm2_dma_kernel<9, false, false>);
+        return accumulate ? launch(igemm2_dma_kernel<9, true, true>) : launch(igemm2_dma_kernel<9, true, false>);
     }
     return T == 1 ? launch_taps<1>(p, c.id, stream) : launch_taps<9>(p, c.id, stream);
 }
