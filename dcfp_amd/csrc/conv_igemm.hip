@@ -102,7 +102,8 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     const int Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
     if (dcfp_igemm2_dma_shape(d->KH * d->KW, M, Ck, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd, d->pad, HiWi,
                               pass == DCFP_CONV_FWD ? d->Wout : d->W))
-        return snprintf(buf, buf_len, "igemm2_dma_kernel<%d>", d->KH * d->KW);
+        return snprintf(buf, buf_len, "igemm2_dma_kernel<%d,%s>", d->KH * d->KW,
+                        (d->KH == 3 && ((d->pad | d->dil) & 3) != 0) ? "true" : "false");   // <TAPS, MIXED>
     return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW, dcfp_igemm2_cfg_args(M, px, sd));
 }
 

@@ -396,6 +396,209 @@ int num_cus() {
     return n;
 }
 
+// The 256 x 256 tile with both operands staged by LDS-DMA (`buffer_load ... lds`), for stride-1
+// same-size convs whose rows are multiples of 16 pixels: a K-step is then 16 consecutive pixels
+// of one image row, so a wave instruction copies the 16-pixel runs of 16 rows (dy channels, or
+// (ci, tap) rows of x at that tap's shift) straight into the LDS image - no staging registers,
+// no ds_write pass.  The image is [row][16 px] UNPADDED (LDS-DMA writes lane-linearly), made
+// conflict-free for the 16-byte fragment reads by an XOR swizzle applied on the SOURCE side:
+// 16-byte slot sl of row r holds pixel quad sl ^ ((r >> 2) & 3).  MIXED: some tap shifts the
+// columns by a non-multiple of 4 (dilation 1, 2), so quads straddle the row ends: x is then
+// copied pixel by pixel (dword copies, 4 rows per instruction); padding = out-of-range offsets.
+template <int TAPS, bool MIXED>
+__global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
+    constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][BM][BK]
+    float* Bs = smem + 2 * BM * BK;     // [2][BN][BK]
+    const int tiles = p.tiles_m * p.tiles_n;
+    int split, tile;
+    {
+        const int full = (p.splits / 8) * 8;
+        const int gsz = 8 * tiles;
+        const int b = blockIdx.x;
+        if (b < (full / 8) * gsz) {
+            const int g = b / gsz, r = b - g * gsz;
+            tile = r >> 3;
+            split = g * 8 + (r & 7);
+        } else {
+            const int r = b - (full / 8) * gsz;
+            const int rem = p.splits - full;
+            tile = r / rem;
+            split = full + (r - tile * rem);
+        }
+    }
+    const int mt = tile / p.tiles_n, ntile = tile - mt * p.tiles_n;
+    const int m0 = mt * BM, n0 = ntile * BN;
+    const int kbeg = split * p.kchunk;
+    int kend = kbeg + p.kchunk;
+    if (kend > p.Kpix || kend < kbeg) kend = p.Kpix;
+    const int nk = (kend - kbeg) / BK;                  // kchunk, Kpix are multiples of 16 here
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int img0 = kbeg / p.P;
+    const int HW = p.H * p.W;
+    typedef unsigned u32x4 __attribute__((vector_size(16)));
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto make_desc = [](const void* base) {
+        const unsigned long long a = (unsigned long long)base;
+        u32x4 d = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, kMaxRecords, 0x00020000u};
+        return d;
+    };
+    const u32x4 a_desc = make_desc(p.dy + (long long)img0 * p.dy_nstride);
+    const u32x4 b_desc = make_desc(p.x + (long long)img0 * p.x_nstride);
+    const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
+
+    // ---- A (dy): instruction q of this wave copies rows 64*wid + 16q + (lane >> 2); the lane's slot
+    // lane & 3 receives pixel quad (lane & 3) ^ ((lane >> 4) & 3)
+    const int gq = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned a_voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int m = m0 + 64 * wid + 16 * q + (lane >> 2);
+        m = m < p.M ? m : p.M - 1;
+        a_voff[q] = (unsigned)(m * p.P + 4 * gq) * 4u;
+    }
+    // ---- B (x at the row's tap shift): quad copies use the same lane -> (row, quad) map; dword copies
+    // (MIXED) cover rows 64*wid + 16q + 4e + (lane >> 4), slot (lane >> 2) & 3 -> quad slot ^ e, pixel lane & 3
+    int bq_c[4], bq_dh[4], bq_dw[4];           // per quad-instruction q: channel offset, tap shift
+    int bd_c[16], bd_dh[16], bd_dw[16];        // per dword-instruction (q, e)
+    auto row_tap = [&](int row, int& coff, int& dh, int& dw) {
+        int nn = n0 + row;
+        nn = nn < p.Nn ? nn : p.Nn - 1;
+        const int ci = nn / TAPS, t = nn - ci * TAPS;
+        const int kh = (TAPS == 9) ? t / 3 : 0, kw = (TAPS == 9) ? t - kh * 3 : 0;
+        dh = kh * p.dil - p.pad; dw = kw * p.dil - p.pad;
+        coff = ci * HW;
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row_tap(64 * wid + 16 * q + (lane >> 2), bq_c[q], bq_dh[q], bq_dw[q]);
+    if constexpr (MIXED) {
+#pragma unroll
+        for (int qe = 0; qe < 16; ++qe) row_tap(64 * wid + 4 * qe + (lane >> 4), bd_c[qe], bd_dh[qe], bd_dw[qe]);
+    }
+    const int gd = ((lane >> 2) & 3);          // dword copies: slot; quad = slot ^ e, element lane & 3
+
+    // position of the K-step the loader copies next: image (relative to img0), row, first column
+    int c_im = 0, c_oh, c_ow;
+    {
+        const int pq = kbeg - img0 * p.P;
+        c_oh = pq / p.Wo; c_ow = pq - c_oh * p.Wo;
+    }
+    auto issue = [&](int buf) {
+        // (uniform values; readfirstlane makes the compiler keep them in SGPRs for the asm operands)
+        const unsigned a_s = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.dy_nstride + c_oh * p.Wo + c_ow) * 4u);
+        const unsigned b_img = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.x_nstride) * 4u);
+        const int oh = c_oh, ow = c_ow;
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BM + 64 * wid + 16 * q) * BK) * 4u);
+            const unsigned av = a_voff[q], as_ = a_s;
+            const u32x4 ad = a_desc;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory");
+        });
+        if constexpr (!MIXED) {
+            static_for<0, 4>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 16 * q) * BK) * 4u);
+                const int hh = oh + bq_dh[q], ww = ow + 4 * gq + bq_dw[q];
+                const bool ok = hh >= 0 && hh < p.H && ww >= 0 && ww + 3 < p.W;
+                const unsigned bv = ok ? (unsigned)(bq_c[q] + hh * p.W + ww) * 4u : kOob;
+                const unsigned bs_ = b_img;
+                const u32x4 bd = b_desc;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
+            });
+        } else {
+            static_for<0, 16>([&](auto qe_) {
+                constexpr int qe = decltype(qe_)::value;
+                constexpr int e = qe & 3;
+                const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 4 * qe) * BK) * 4u);
+                const int hh = oh + bd_dh[qe], ww = ow + 4 * (gd ^ e) + (lane & 3) + bd_dw[qe];
+                const bool ok = hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+                const unsigned bv = ok ? (unsigned)(bd_c[qe] + hh * p.W + ww) * 4u : kOob;
+                const unsigned bs_ = b_img;
+                const u32x4 bd = b_desc;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
+            });
+        }
+        c_ow += BK;
+        if (c_ow >= p.Wo) { c_ow = 0; if (++c_oh >= p.Ho) { c_oh = 0; ++c_im; } }
+    };
+    auto retire = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) issue(0);
+    retire();
+    // fragment reads: lane (l31, lhi) reads 16-byte slot ((2 kq + lhi) ^ ((l31 >> 2) & 3)) of its row
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = (wm * (TM * 32) + l31) * BK, b_row = (wn * (TN * 32) + l31) * BK;
+    const int f0 = 4 * ((0 + lhi) ^ sw), f1 = 4 * ((2 + lhi) ^ sw);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1);
+        const float* a = As + cur * (BM * BK) + a_row;
+        const float* b = Bs + cur * (BN * BK) + b_row;
+        f32x4 af[2][TM], bf[2][TN];
+        static_for<0, TM>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK + f0);
+            af[1][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK + f1);
+        });
+        static_for<0, TN>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * BK + f0);
+            bf[1][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * BK + f1);
+        });
+        static_for<0, 8>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            constexpr int kq = s / 4, e = s % 4;
+            static_for<0, TM>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                static_for<0, TN>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][i][e], bf[kq][j][e], acc[i][j], 0, 0, 0);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        retire();
+    }
+
+    float* o = p.out + (long long)split * p.M * p.Nn;
+    int ncol = n0 + wn * (TN * 32) + l31;
+    asm volatile("" : "+v"(ncol));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int m = m0 + wm * (TM * 32) + i * 32 + row;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nn = ncol + j * 32;
+                if (nn < p.Nn) o[(long long)m * p.Nn + nn] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 struct Plan {
     int bm, bn, cfg;  // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave)
     int tiles_m, tiles_n, splits, kchunk;
@@ -482,6 +685,26 @@ int launch_cfg(const WgradParams& p, long long blocks, hipStream_t stream) {
     return e == hipSuccess ? DCFP_OK : (int)e;
 }
 
+// shapes the LDS-DMA kernel takes: 256 x 256 tile, stride 1, output = input size, rows of 16 k pixels
+static bool wgrad_dma_ok(const DcfpConvDesc* d, int cfg) {
+    static const bool on = [] { const char* e = getenv("DCFP_WGRAD_DMA"); return !e || atoi(e) != 0; }();   // =0: off
+    static const bool mixed_too = [] { const char* e = getenv("DCFP_WGRAD_DMA_MIXED"); return e && atoi(e) != 0; }();
+    const bool mixed = d->KH == 3 && ((d->pad | d->dil) & 3) != 0;
+    // same-box A/B: +17 % where every tap keeps quads aligned (1x1, dilation 4/8/12/...), -1 % with the
+    // dword copies that dilation 1/2 need - those stay on the register-staged kernel
+    return on && cfg == 0 && d->stride == 1 && d->Hout == d->H && d->Wout == d->W && d->W % 16 == 0 &&
+           (!mixed || mixed_too);
+}
+static bool wgrad_dma_mixed(const DcfpConvDesc* d) { return d->KH == 3 && ((d->pad | d->dil) & 3) != 0; }
+
+template <int TAPS, bool MIXED>
+int launch_dma(const WgradParams& p, long long blocks, hipStream_t stream) {
+    const size_t lds = (size_t)2 * 512 * BK * sizeof(float);
+    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DCFP_OK : (int)e;
+}
+
 template <int TAPS>
 int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
     const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
@@ -499,6 +722,8 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : "2,2,1,1";
     if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
+    if (wgrad_dma_ok(d, pl.cfg))
+        return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,%s>", d->KH * d->KW, wgrad_dma_mixed(d) ? "true" : "false");
     return snprintf(buf, buf_len, "wgrad2_kernel<%d,%s>", d->KH * d->KW, args);
 }
 
@@ -545,7 +770,13 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         rc = dcfp_wgrad3_launch(dy, p.dy_nstride, x, p.x_nstride, p.out, d->N, d->Cout, d->Cin, T, d->H, d->W,
                                 d->Hout, d->Wout, d->pad, d->dil, p.Kpix, pl.kchunk, pl.splits, pl.tiles_m,
                                 pl.tiles_n, dcfp_s(stream));
-    else
+    else if (wgrad_dma_ok(d, pl.cfg)) {
+        const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
+        if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+        rc = T == 1 ? launch_dma<1, false>(p, blocks, dcfp_s(stream))
+                    : wgrad_dma_mixed(d) ? launch_dma<9, true>(p, blocks, dcfp_s(stream))
+                                         : launch_dma<9, false>(p, blocks, dcfp_s(stream));
+    } else
         rc = T == 1 ? launch_taps<1>(p, pl, dcfp_s(stream)) : launch_taps<9>(p, pl, dcfp_s(stream));
     if (rc) return rc;
     if (pl.splits > 1) {
