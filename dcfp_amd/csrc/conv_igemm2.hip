@@ -479,8 +479,9 @@ igemm2_kernel(const Igemm2Params p) {
 // channels of Wp, or 256 pixels of one input channel) straight into the [k][256] LDS image the
 // fragment reads already use - no staging VGPRs, no ds_write pass, no address arithmetic in the
 // loop; the copy of tile kt+1 is issued before the 128 MFMAs of tile kt and the step's barrier
-// (which waits vmcnt(0)) retires it.  Interior tiles only (M, P multiples of 256, Ck of 16); same-box
-// A/B against the register-staged kernel: +6...+11 % (layer4 1x1 dgrad 130 -> 142 TF = 90 % of peak).
+// (which waits vmcnt(0)) retires it.  Ragged shapes (pruned widths) work too: rows past M meet the zero
+// rows of Wp, channel rows past Ck and pixels past P are out of the descriptor's range (zeros), and
+// edge tiles take a predicated store path.  Same-box A/B against the register-staged kernel: +6...+11 % (layer4 1x1 dgrad 130 -> 142 TF = 90 % of peak).
 // DCFP_IGEMM_DMA=0 switches it off.
 // TAPS = 9: every K-step copies the activation rows of ONE tap, shifted by that tap's (dh, dw);
 // lanes whose pixels fall into the padding use an out-of-range offset (the copy writes zeros).  With
@@ -516,13 +517,16 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     }
     // this lane's pixels: the quad 4*lane.. (16-byte copies) and pixels 64 s + lane (dword copies)
     int q_oh, q_ow, s_oh[4], s_ow[4];
+    bool q_in, s_in[4] = {true, true, true, true};     // pixels past P (last tile of an image) copy zeros
     {
         const int pp = p0 + 4 * lane;
+        q_in = pp < p.P;                                // P % 4 == 0: a quad is inside or outside as a whole
         q_oh = pp / p.Wo; q_ow = pp - q_oh * p.Wo;
         if constexpr (MIXED) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ps = p0 + 64 * e + lane;
+                s_in[e] = ps < p.P;
                 s_oh[e] = ps / p.Wo; s_ow[e] = ps - s_oh[e] * p.Wo;
             }
         }
@@ -539,14 +543,14 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         tap_quads = !MIXED || (offw & 3) == 0;
         {
             const int hh = q_oh + offh, ww = q_ow + offw;
-            const bool ok = hh >= 0 && hh < p.Hi && ww >= 0 && ww + 3 < p.Wi;
+            const bool ok = q_in && hh >= 0 && hh < p.Hi && ww >= 0 && ww + 3 < p.Wi;
             boff4 = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
         }
         if constexpr (MIXED) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int hh = s_oh[e] + offh, ww = s_ow[e] + offw;
-                const bool ok = hh >= 0 && hh < p.Hi && ww >= 0 && ww < p.Wi;
+                const bool ok = s_in[e] && hh >= 0 && hh < p.Hi && ww >= 0 && ww < p.Wi;
                 boff1[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
             }
         }
@@ -566,7 +570,8 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
     auto issue = [&](int buf) {      // copy tile (ld_t, ld_cb) into LDS buffer `buf`, then step the loader
         const unsigned a_s = (unsigned)((ld_t * p.CkP + ld_cb * BK) * p.Mpad + m0) * 4u;
-        const unsigned b_s = (unsigned)(ld_cb * BK * HiWi) * 4u;
+        const unsigned b_cb = (unsigned)(ld_cb * BK * HiWi) * 4u;   // in the VGPR offset: the descriptor's
+        const unsigned b_s = 0;                                      // bound must see it (rows past Ck -> zeros)
         static_for<0, 4>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid + q) * BM) * 4u);
@@ -576,13 +581,13 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory");
             if (tap_quads) {
-                const unsigned bv = boff4 + b_row[q];
+                const unsigned bv = boff4 + b_row[q] + b_cb;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                              :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
             } else if constexpr (MIXED) {
                 static_for<0, 4>([&](auto e_) {
                     constexpr int e = decltype(e_)::value;
-                    const unsigned bv = boff1[e] + b_row[q];
+                    const unsigned bv = boff1[e] + b_row[q] + b_cb;
                     const unsigned le = lb + 256u * e, bs2 = bs_;
                     const u32x4 bd2 = bd;      // (asm operands must be locals of the innermost lambda)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
@@ -638,6 +643,24 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         retire();
     }
     float* o_img = p.out + (long long)img * p.out_nstride;
+    if (m0 + BM > p.M || p0 + BN > p.P) {     // edge tile (block-uniform): predicated stores
+        int pix = p0 + wn * (TN * 32) + TN * l31;
+        asm volatile("" : "+v"(pix));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int m = m0 + wm * (TM * 32) + TM * row + i;
+                if (m >= p.M || pix >= p.P) continue;      // P % 4 == 0: the lane's 4 pixels are in or out together
+                float* dst = o_img + (long long)m * p.P + pix;
+                f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                if constexpr (ACC) v += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        return;
+    }
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         o_img + (long long)m0 * p.P + p0, 0, 0x7ffffffcu, 0x00020000);
     unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
@@ -767,9 +790,7 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo) {
     static const bool dma = [] { const char* e = getenv("DCFP_IGEMM_DMA"); return !e || atoi(e) != 0; }();   // =0: off
     static const bool dma9 = [] { const char* e = getenv("DCFP_IGEMM_DMA9"); return !e || atoi(e) != 0; }();
-    if (!dma || pick_cfg(M, px, sd).id != 4 || sn != 1 || sd != 1 || P % 256 != 0 || M % 256 != 0 ||
-        Ck % 16 != 0 || HiWi != P || Wo % 4 != 0)
-        return false;
+    if (!dma || pick_cfg(M, px, sd).id != 4 || sn != 1 || sd != 1 || HiWi != P || Wo % 4 != 0) return false;
     return T == 1 ? off0 == 0 : dma9;
 }
 
