@@ -35,6 +35,7 @@ class SgdEntry(C.Structure):
 
 SGD_CHUNK = 16384
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+E_BADDESC, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3   # DCFP_E_* of include/dcfp_hip.h
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
@@ -55,6 +56,7 @@ SIGNATURES = {
                                     _P, _Z, _P]),
     "dcfp_bn_update_running_f32": (_I, [_P, _P, _I, _F, _F, _P, _P, _P, _P]),
     "dcfp_syncbn_combine_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "dcfp_bn_apply_relu_mask_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "dcfp_conv2d_fwd_stat_slots": (_L, [_D, _P, _L]),
     "dcfp_conv2d_fwd_stats_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _P, _Z, _P]),
     "dcfp_bn_stats_from_partials_f32": (_I, [_P, _L, _I, _I, _P, _P, _P]),

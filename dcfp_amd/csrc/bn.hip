@@ -30,7 +30,7 @@ BnPlan bn_plan(int N, int C, int HW) {
     long long chunks = by_size < by_grid ? by_size : by_grid;
     if (chunks < 1) chunks = 1;
     long long ce = (E + chunks - 1) / chunks;
-    ce = (ce + 3) / 4 * 4;
+    ce = (ce + 1023) / 1024 * 1024;   // whole wave iterations (256 elements per wave): the bit-mask ReLU path needs them
     chunks = (E + ce - 1) / ce;
     if (chunks < 1) chunks = 1;
     BnPlan p;
@@ -96,14 +96,23 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, int HW, long 
     var[c] = (float)v;
 }
 
+// ReLU bit mask of a residual BatchNorm (one bit per element instead of re-reading the 4-byte output
+// in both backward kernels).  Layout per (n,c) row, HW % 256 == 0: a wave iteration covers 256
+// consecutive pixels (lane l holds pixels 4l..4l+3); word 4*(i/256) + k holds, at bit l, the mask of
+// pixel 256*(i/256) + 4l + k.
+__device__ __forceinline__ bool mask_bit(const unsigned long long* __restrict__ row_words, int i_wave, int k) {
+    const unsigned long long wv = row_words[(i_wave >> 8) * 4 + k];
+    return (wv >> (threadIdx.x & 63)) & 1ull;
+}
+
 // ---- apply: one (n,c) row segment per block
-template <bool VEC>
+template <bool VEC, bool MASK = false>
 __global__ void __launch_bounds__(kThreads)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                 const float* __restrict__ var, const float* __restrict__ gamma,
                 const float* __restrict__ beta, float eps, const float* __restrict__ res,
                 int relu, float* __restrict__ y, long long y_nstride, int C, int HW,
-                int colchunks, int cols_per_block) {
+                int colchunks, int cols_per_block, unsigned long long* __restrict__ mask = nullptr) {
     const long long row = blockIdx.x / colchunks;
     const int chunk = blockIdx.x - (int)(row * colchunks);
     const int n = (int)(row / C), c = (int)(row - (long long)n * C);
@@ -130,6 +139,14 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
             if (relu) {
                 o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
                 o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if constexpr (MASK) {
+                const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f);
+                const unsigned long long b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* mw = mask + row * (HW >> 6) + (i >> 8) * 4;
+                    mw[0] = b0; mw[1] = b1; mw[2] = b2; mw[3] = b3;
+                }
             }
             *reinterpret_cast<float4*>(yr + i) = o;
         }
@@ -180,6 +197,12 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
                 g.y = bn_val(xv.y, mu, istd, gm, bt) > 0.f ? g.y : 0.f;
                 g.z = bn_val(xv.z, mu, istd, gm, bt) > 0.f ? g.z : 0.f;
                 g.w = bn_val(xv.w, mu, istd, gm, bt) > 0.f ? g.w : 0.f;
+            } else if (RELU == 3) {   // y carries the bit mask of dcfp_bn_apply_relu_mask_f32
+                const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(y) +
+                                               (n * C + c) * (long long)(HW >> 6);
+                const int iw = i - 4 * (int)(threadIdx.x & 63);
+                g.x = mask_bit(mw, iw, 0) ? g.x : 0.f; g.y = mask_bit(mw, iw, 1) ? g.y : 0.f;
+                g.z = mask_bit(mw, iw, 2) ? g.z : 0.f; g.w = mask_bit(mw, iw, 3) ? g.w : 0.f;
             }
             s1 += (g.x + g.y) + (g.z + g.w);
             s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
@@ -336,6 +359,11 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
                 g.y = bn_val(xv.y, mu, istd, gm, bt) > 0.f ? g.y : 0.f;
                 g.z = bn_val(xv.z, mu, istd, gm, bt) > 0.f ? g.z : 0.f;
                 g.w = bn_val(xv.w, mu, istd, gm, bt) > 0.f ? g.w : 0.f;
+            } else if (RELU == 3) {
+                const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(y) + row * (HW >> 6);
+                const int iw = i - 4 * (int)(threadIdx.x & 63);
+                g.x = mask_bit(mw, iw, 0) ? g.x : 0.f; g.y = mask_bit(mw, iw, 1) ? g.y : 0.f;
+                g.z = mask_bit(mw, iw, 2) ? g.z : 0.f; g.w = mask_bit(mw, iw, 3) ? g.w : 0.f;
             }
             float4 o;
             o.x = (g.x - mean_dy - (xv.x - mu) * k) * gi;
@@ -412,6 +440,25 @@ extern "C" int dcfp_bn_apply_f32(const float* x, const float* mean, const float*
     DCFP_RETURN_LAUNCH();
 }
 
+// y = relu(BN(x) [+ residual]) and the 1-bit-per-element ReLU mask the backward kernels take with relu == 3
+// (through their `y` argument) instead of re-reading y.  Needs HW % 256 == 0 and 16-byte aligned rows.
+extern "C" int dcfp_bn_apply_relu_mask_f32(const float* x, const float* mean, const float* var,
+                                           const float* gamma, const float* beta, float eps,
+                                           const float* residual, float* y, void* relu_mask,
+                                           int N, int C, int HW, dcfp_stream_t stream) {
+    if (!x || !mean || !var || !gamma || !beta || !y || !relu_mask || N <= 0 || C <= 0 || HW <= 0)
+        return DCFP_E_BADDESC;
+    const bool vec = dcfp_aligned16(x) && dcfp_aligned16(y) && (!residual || dcfp_aligned16(residual));
+    if (!vec || HW % 256 != 0 || (reinterpret_cast<uintptr_t>(relu_mask) & 7u)) return DCFP_E_UNSUPPORTED;
+    const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
+    const long long blocks = (long long)N * C * colchunks;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3((unsigned)blocks), dim3(kThreads), 0, dcfp_s(stream),
+                       x, mean, var, gamma, beta, eps, residual, 1, y, (long long)C * HW, C, HW, colchunks,
+                       kColsPerBlock, static_cast<unsigned long long*>(relu_mask));
+    DCFP_RETURN_LAUNCH();
+}
+
 extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                                       const float* y, int64_t y_nstride, const float* mean,
                                       const float* var, const float* gamma, const float* beta,
@@ -421,8 +468,8 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
     if (dgamma && !var) return DCFP_E_BADDESC;
     if (!dy || !x || !mean || !sum_dy || !sum_dy_xmu || N <= 0 || C <= 0 || HW <= 0)
         return DCFP_E_BADDESC;
-    if (relu < 0 || relu > 2) return DCFP_E_BADDESC;
-    if (relu == 1 && !y) return DCFP_E_BADDESC;
+    if (relu < 0 || relu > 3) return DCFP_E_BADDESC;
+    if ((relu == 1 || relu == 3) && !y) return DCFP_E_BADDESC;
     if (relu == 2 && (!var || !gamma || !beta)) return DCFP_E_BADDESC;
     if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
     if (y_nstride == 0) y_nstride = (int64_t)C * HW;
@@ -438,7 +485,8 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
     hipLaunchKernelGGL((bn_bwd_reduce_partial_kernel<V, R>), grid, dim3(kThreads), 0,             \
                        dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
                        mean, var, gamma, beta, eps, C, HW, E, p.chunk_elems, p.chunks, part)
-    if (vec) { if (relu == 2) LAUNCH_RED(true, 2); else if (relu == 1) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
+    if (relu == 3 && !(vec && HW % 256 == 0 && dy_nstride == (int64_t)C * HW)) return DCFP_E_UNSUPPORTED;
+    if (vec) { if (relu == 3) LAUNCH_RED(true, 3); else if (relu == 2) LAUNCH_RED(true, 2); else if (relu == 1) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
     else     { if (relu == 2) LAUNCH_RED(false, 2); else if (relu == 1) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
     hipLaunchKernelGGL(bn_pair_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C,
@@ -466,7 +514,7 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
     if (!dy || !x || !mean || !var || !gamma || !sum_dy || !sum_dy_xmu || !dx || N <= 0 ||
         C <= 0 || HW <= 0 || (!count_dev && !(count > 0.f)))
         return DCFP_E_BADDESC;
-    if (relu < 0 || relu > 2 || (relu == 1 && !y) || (relu == 2 && !beta)) return DCFP_E_BADDESC;
+    if (relu < 0 || relu > 3 || ((relu == 1 || relu == 3) && !y) || (relu == 2 && !beta)) return DCFP_E_BADDESC;
     if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
     if (y_nstride == 0) y_nstride = (int64_t)C * HW;
     const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
@@ -482,7 +530,8 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
                        mean, var, gamma, beta, eps, sum_dy, sum_dy_xmu, inv_count, count_dev, dx, \
                        d_residual, C,                                                             \
                        HW, colchunks, kColsPerBlock)
-    if (vec) { if (relu == 2) LAUNCH_APP(true, 2); else if (relu == 1) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
+    if (relu == 3 && !(vec && HW % 256 == 0)) return DCFP_E_UNSUPPORTED;
+    if (vec) { if (relu == 3) LAUNCH_APP(true, 3); else if (relu == 2) LAUNCH_APP(true, 2); else if (relu == 1) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
     else     { if (relu == 2) LAUNCH_APP(false, 2); else if (relu == 1) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
 #undef LAUNCH_APP
     DCFP_RETURN_LAUNCH();

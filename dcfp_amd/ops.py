@@ -109,6 +109,9 @@ def _desc(xshape, wshape, stride, pad, dil):
 # the BatchNorm behind them.  Measured neutral on MI355X (BN -6 ms/step, conv epilogues +5 ms/step:
 # 640 cross-lane exchanges per wave and tile), so the separate bn_stats pass stays the default.
 FUSE_BN_STATS = os.environ.get("DCFP_FUSED_BN_STATS", "") not in ("", "0")
+# The residual BatchNorm of a Bottleneck keeps its ReLU mask as one bit per element for the backward
+# (instead of two re-reads of the 4-byte block output); DCFP_BN_RELU_BITMASK=0 switches it off.
+BN_RELU_BITMASK = os.environ.get("DCFP_BN_RELU_BITMASK", "1") not in ("0",)
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
@@ -233,16 +236,38 @@ def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
     return y
 
 
+def bn_apply_relu_mask(x, mean, var, gamma, beta, eps, residual):
+    """y = relu(BN(x) + residual) plus the ReLU mask as one bit per element (int64 words), or None where
+    the library has no mask path for the shape (HW % 256 != 0)."""
+    N, Cc, H, W = x.shape
+    if (H * W) % 256 != 0:
+        return None
+    x = x.contiguous(); residual = residual.contiguous()
+    y = torch.empty_like(x)
+    mask = torch.empty(x.numel() // 64, dtype=torch.int64, device=x.device)
+    rc = [0]
+
+    def run():
+        rc[0] = _lib.lib().dcfp_bn_apply_relu_mask_f32(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps),
+                                                       _p(residual), _p(y), _p(mask), N, Cc, H * W, _stream())
+    _timed("bn_apply", None, 12.125 * x.numel(), run)
+    if rc[0] == _lib.E_UNSUPPORTED:
+        return None
+    check(rc[0], "bn_apply_relu_mask")
+    return y, mask
+
+
 def bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu):
-    """relu: 0 none, 1 mask from y, 2 mask re-derived from x (forward had no residual)."""
+    """relu: 0 none, 1 mask from y, 2 mask re-derived from x (forward had no residual), 3 `y` is the
+    1-bit-per-element mask written by bn_apply_relu_mask."""
     N, Cc, H, W = x.shape
     dy, dns = _batch_strided(dy)
     L = _lib.lib()
     ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
     s = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
     s1, s2, dgamma = s[0], s[1], s[2]
-    _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu == 1 else 0.0)) * x.numel(), lambda: check(
-        L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu == 1 else None, 0, _p(mean), _p(var),
+    _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu == 1 else 0.125 if relu == 3 else 0.0)) * x.numel(), lambda: check(
+        L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu in (1, 3) else None, 0, _p(mean), _p(var),
                                  _p(gamma), _p(beta), float(eps), int(relu), N, Cc, H * W, _p(s1), _p(s2),
                                  _p(dgamma), _p(ws), ws.numel(), _stream()),
         "bn_bwd_reduce"))
@@ -254,11 +279,11 @@ def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, wan
     dy, dns = _batch_strided(dy)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual else None
-    nbytes = (12.0 + (4.0 if relu == 1 else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
+    nbytes = (12.0 + (4.0 if relu == 1 else 0.125 if relu == 3 else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
     count_dev = count if isinstance(count, torch.Tensor) else None   # SyncBN: global count on device
     count_host = 0.0 if count_dev is not None else float(count)
     _timed("bn_bwd_apply", None, nbytes, lambda: check(
-        _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu == 1 else None, 0, _p(mean),
+        _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu in (1, 3) else None, 0, _p(mean),
                                          _p(var), _p(gamma), _p(beta), float(eps), _p(s1), _p(s2), count_host,
                                          _p(count_dev), int(relu), _p(dx), _p(dres), N, Cc, H * W,
                                          _stream()),
@@ -326,7 +351,7 @@ def sync_bn_bwd_sums(s1, s2, group):
 
 
 def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, training,
-                    momentum, eps, sync, stats=None):
+                    momentum, eps, sync, stats=None, want_mask=False):
     """Shared BN(+ReLU)(+residual) forward: returns (y, state) with state =
     (mean, var, count, group) for the backward.  `stats` = this rank's (mean, biased var) when the
     producing conv already emitted them (conv2d_fwd(..., want_stats=True))."""
@@ -346,6 +371,10 @@ def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, t
                 _p(cdev), _p(running_mean), _p(running_var), _stream()), "bn_update_running")
     else:
         mean, var = running_mean, running_var
+    if want_mask and relu and residual is not None and BN_RELU_BITMASK:
+        ym = bn_apply_relu_mask(x, mean, var, gamma, beta, eps, residual)
+        if ym is not None:
+            return ym[0], (mean, var, count, group, ym[1])
     y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
     return y, (mean, var, count, group)
 
@@ -355,8 +384,12 @@ def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res
     (the gradient all-reduce averages them); under SyncBN the sums entering dx are global.
     `y` is only needed for the ReLU mask of a BN that had a residual input; otherwise the mask
     is re-derived from x inside the kernels (pass y=None)."""
-    mean, var, count, group = state
-    relu = (1 if y is not None else 2) if relu else 0
+    mean, var, count, group = state[:4]
+    mask = state[4] if len(state) > 4 else None
+    if relu and mask is not None:      # residual BN whose forward kept the ReLU mask as bits
+        relu, y = 3, mask
+    else:
+        relu = (1 if y is not None else 2) if relu else 0
     s1, s2, dgamma = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu)
     # the SyncBN exchange reduces (s1, s2) in place; dbeta stays this rank's sum
     dbeta = s1.clone() if (training and group is not None) else s1
@@ -381,7 +414,7 @@ class BatchNormActFn(torch.autograd.Function):
         x = x.contiguous()
         y, state = bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu,
                                    training, momentum, eps, sync)
-        mean, var, count, group = state
+        mean, var, count, group = state[:4]
         # y is saved only where the ReLU mask cannot be re-derived from x (residual input)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var, gamma, beta,
                               count if isinstance(count, torch.Tensor) else None)
@@ -434,7 +467,8 @@ class BottleneckFn(torch.autograd.Function):
             res, std = bn_forward_impl(cd, gd, bd, bnargs[3][0], bnargs[3][1], None, False, *bnargs[3][2:], stats=sd)
         else:
             cd, res, std = None, x, None
-        out, st3 = bn_forward_impl(c3, g3, b3, bnargs[2][0], bnargs[2][1], res, True, *bnargs[2][2:], stats=s3)
+        out, st3 = bn_forward_impl(c3, g3, b3, bnargs[2][0], bnargs[2][1], res, True, *bnargs[2][2:], stats=s3,
+                                   want_mask=True)
         ctx.has_ds = has_ds
         ctx.cfg = (stride, dil, [a[2] for a in bnargs], [a[4] for a in bnargs])
         ctx.states = (st1, st2, st3, std)

@@ -110,7 +110,8 @@ int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
  *   sum_dy[c] = sum g ;  sum_dy_xmu[c] = sum g*(x-mean[c])
  * (dbeta = sum_dy; dgamma = sum_dy_xmu * rsqrt(var+eps): the per-filter statistic
  * that feeds the EIC score, pruners/dcfp_pruner.py:18).
- * relu: 0 no ReLU (mask = 1); 1 mask = (y > 0) read from the saved output y;
+ * relu: 0 no ReLU (mask = 1); 1 mask = (y > 0) read from the saved output y; 3 `y` is the bit mask
+ *       written by dcfp_bn_apply_relu_mask_f32;
  *       2 mask re-derived from x with the forward's own expression (only valid when the
  *         forward had no residual input; needs var/gamma/beta, y may be NULL). */
 int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
@@ -142,6 +143,13 @@ int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean
 int dcfp_bn_update_running_f32(const float* mean, const float* var, int C, float momentum,
                                float count, const float* count_dev, float* running_mean,
                                float* running_var, dcfp_stream_t stream);
+/* Forward of a BatchNorm + ReLU with a residual input that ALSO writes the ReLU mask as one bit per
+ * element (N*C*HW/8 bytes, 8-byte aligned; needs HW % 256 == 0).  The backward kernels take the mask
+ * through their `y` argument with relu == 3 instead of re-reading the 4-byte output (resnet.py:52-56). */
+int dcfp_bn_apply_relu_mask_f32(const float* x, const float* mean, const float* var,
+                                const float* gamma, const float* beta, float eps,
+                                const float* residual, float* y, void* relu_mask,
+                                int N, int C, int HW, dcfp_stream_t stream);
 /* Backward stage 2: dx = gamma*istd*( g - sum_dy/M - (x-mean)*istd^2*sum_dy_xmu/M ),
  * M = count (N*HW); under SyncBN the global count lives on the device: count_dev (nullable,
  * one float) then overrides `count` without a host round trip.  d_residual (nullable) = g. */

@@ -292,3 +292,30 @@ def test_conv_fused_bn_stats(cuda, Cout, k):
     assert ((stats[1].double().cpu() - v64.cpu()).abs() / v64.cpu()).max().item() < 2e-6
     m2, v2 = ops.bn_stats(y)
     assert max_err(stats[0], m2) < 2e-6 and ((stats[1] - v2).abs() / v2).max().item() < 2e-6
+
+
+def test_bn_relu_bitmask_path(cuda):
+    """Residual BatchNorm+ReLU whose forward writes the ReLU mask as one bit per element and whose
+    backward kernels read those bits (relu mode 3) — against the variant that re-reads y (mode 1)."""
+    from dcfp_amd import ops
+    g = torch.Generator().manual_seed(21)
+    shape = (3, 40, 16, 48)                       # HW = 768 = 3 x 256
+    x = (torch.randn(shape, generator=g) * 1.3).to(cuda)
+    res = torch.randn(shape, generator=g).to(cuda)
+    dy = torch.randn(shape, generator=g).to(cuda)
+    gamma = (torch.rand(40, generator=g) + 0.5).to(cuda); beta = (torch.randn(40, generator=g) * 0.2).to(cuda)
+    mean, var = ops.bn_stats(x)
+    ym = ops.bn_apply_relu_mask(x, mean, var, gamma, beta, 1e-5, res)
+    assert ym is not None
+    y, mask = ym
+    y_ref = ops.bn_apply(x, mean, var, gamma, beta, 1e-5, res, True)
+    assert torch.equal(y, y_ref)
+    s1a, s2a, dga = ops.bn_bwd_reduce(dy, x, y_ref, mean, var, gamma, beta, 1e-5, 1)
+    s1b, s2b, dgb = ops.bn_bwd_reduce(dy, x, mask, mean, var, gamma, beta, 1e-5, 3)
+    assert torch.equal(s1a, s1b)                   # same mask, same summation order
+    # (the two template instantiations may contract g*(x-mean) differently: last-digit differences)
+    assert rel_err(s2b, s2a) < 1e-6 and rel_err(dgb, dga) < 1e-6
+    cnt = float(shape[0] * shape[2] * shape[3])
+    dxa, dra = ops.bn_bwd_apply(dy, x, y_ref, mean, var, gamma, beta, 1e-5, s1a, s2a, cnt, 1, True)
+    dxb, drb = ops.bn_bwd_apply(dy, x, mask, mean, var, gamma, beta, 1e-5, s1a, s2a, cnt, 3, True)
+    assert torch.equal(dxa, dxb) and torch.equal(dra, drb)
