@@ -1,0 +1,182 @@
+"""Parity at BASELINE.json's full sizes.
+
+config (2) DeepLabv3-R50 2x3x512x1024: one whole iteration (forward, CE + 0.4 CE, backward, EIC)
+on the MI355X against the CPU oracle on the same closed-form weights and inputs - the sizes at
+which the 256 x 256 LDS-DMA conv kernels, the split-K wgrads and the multi-block BatchNorm
+reductions are the ones that run (test_model_gpu.py's 65 x 65 cases never reach them).
+
+config (3) DeepLabv3-R101 4x3x1024x2048: too large for the oracle in a test, so size-independent
+properties instead: (a) the step is bit-reproducible (every reduction has a fixed order),
+(b) convolution is exactly homogeneous under a power-of-two scale (x -> 2x doubles every output
+bit for bit in fp32) on the model's FLOP-dominant shapes, (c) accumulate-dgrad == plain dgrad +
+seed, (d) the per-rank mean-of-valid-pixels loss is invariant to relabelling ignored pixels.
+Tolerances: SURVEY.md Appendix D (loss 1e-5 relative, gradients rel-L2 5e-2, logits 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill, model as omodel
+from oracle.train_step import CpuTrainer
+
+pytestmark = pytest.mark.gpu
+BB = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
+
+
+class _DS:
+    ignore_label = 255
+    num_classes = 19
+    class_weights = None
+
+
+def _build(backbone, device, closed_form=True):
+    from dcfp_amd import networks
+    from dcfp_amd.loss.criterion import build_criterions
+    crit = build_criterions("ce", _DS(), {"ds_weight": 0.4})
+    m = networks.deeplabv3.Seg_Model(backbone=backbone, backbone_para=dict(BB), num_classes=19,
+                                     align_corner=True, criterion=crit, deepsup=True)
+    if closed_form:
+        m.load_state_dict(fill.closed_form_state(m.state_dict()))
+    m.conv_deepsup[3].p = 0.0
+    return m.to(device).train()
+
+
+def test_config2_iteration_vs_oracle(cuda):
+    from dcfp_amd import pruners
+    N, H, W = 2, 512, 1024
+    m = _build("resnet50", cuda)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = fill.closed_form_input(N, H, W)
+    lab = fill.closed_form_labels(N, H, W)
+    tp = pruners.dcfp_pruning(m, 0.999)
+    loss = m(x.to(cuda), lab.to(cuda), deepsup=True)["loss"]
+    loss.backward()
+    tp.step(m)
+    torch.cuda.synchronize()
+
+    cfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
+    cpu = CpuTrainer(sd0, cfg, r=0.999)
+    closs, outs, lowres = cpu.step(x, lab, update=False)
+    assert abs(loss.item() - closs) <= 2e-5 * max(1.0, abs(closs)), (loss.item(), closs)
+
+    params = dict(m.named_parameters())
+    worst = []
+    for k, p in cpu.params().items():
+        a = params[k].grad.double().cpu(); b = p.grad.double()
+        worst.append((((a - b).norm() / (b.norm() + 1e-30)).item(), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-2, worst[:5]
+    # the EIC statistic the pruner consumes
+    mine = torch.cat([tp.get_eic()["eic"][n].reshape(-1) for n in cpu.scored]).cpu().numpy()
+    ref = np.concatenate([np.asarray(cpu.eic[n]).reshape(-1) for n in cpu.scored])
+    assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) <= 5e-2
+    # logits of the same (train-mode) forward: low-resolution heads, before the 8x upsample
+    m2 = _build("resnet50", cuda)
+    with torch.no_grad():
+        outs2 = m2(x.to(cuda), None, deepsup=True)
+    # acceptance as SURVEY.md App. D item 1 states it: error against an fp64 run of the oracle, bounded by
+    # 3x the fp32 oracle's own error against that run (fp32-vs-fp32 differences are both runs' rounding)
+    with torch.no_grad():
+        outs64, _, _ = omodel.seg_forward(omodel.clone_state(sd0, torch.float64, requires_grad=False),
+                                          x.double(), cfg, None, True, None)
+    for mine_o, ref32, ref64 in zip(outs2, outs, outs64):
+        err = (mine_o.double().cpu() - ref64).abs().max().item()
+        ref_err = (ref32.detach().double() - ref64).abs().max().item()
+        assert err <= max(1e-3, 3 * ref_err), (err, ref_err, ref64.abs().max().item())
+        rel = ((mine_o.double().cpu() - ref64).norm() / ref64.norm()).item()
+        ref_rel = ((ref32.detach().double() - ref64).norm() / ref64.norm()).item()
+        assert rel <= max(1e-4, 3 * ref_rel), (rel, ref_rel)
+
+
+@pytest.fixture(scope="module")
+def r101(cuda):
+    torch.manual_seed(12345)
+    m = _build("resnet101", cuda, closed_form=False)
+    g = torch.Generator().manual_seed(12345)
+    x = torch.randn(4, 3, 1024, 2048, generator=g).to(cuda)
+    lab = torch.randint(0, 19, (4, 1024, 2048), generator=g)
+    lab[torch.rand(lab.shape, generator=g) < 0.05] = 255
+    yield m, x, lab.to(cuda)
+    del m, x
+    torch.cuda.empty_cache()
+
+
+def _step(m, x, lab):
+    for p in m.parameters():
+        p.grad = None
+    loss = m(x, lab, deepsup=True)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+
+def test_config3_step_is_bit_reproducible(cuda, r101):
+    m, x, lab = r101
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    l1, g1 = _step(m, x, lab)
+    m.load_state_dict(sd)            # running statistics back to where the first step started
+    l2, g2 = _step(m, x, lab)
+    assert torch.isfinite(l1) and torch.equal(l1, l2), (l1.item(), l2.item())
+    bad = [n for (n, _), a, b in zip(m.named_parameters(), g1, g2) if not torch.equal(a, b)]
+    assert not bad, bad[:5]
+    assert all(torch.isfinite(g).all() for g in g1)
+
+
+def test_config3_loss_ignores_ignored_pixels(cuda, r101):
+    """CE is a mean over the rank's own valid pixels (loss/criterion.py:60): what the image holds
+    under an ignored label cannot matter, and ignoring MORE pixels changes the divisor."""
+    m, x, lab = r101
+    with torch.no_grad():
+        a = m(x, lab, deepsup=True)["loss"]
+        lab2 = lab.clone(); lab2[:, ::2, :] = 255
+        b = m(x, lab2, deepsup=True)["loss"]
+        lab3 = lab.clone(); lab3[:, 1::2, :] = 255
+        c = m(x, lab3, deepsup=True)["loss"]
+        n2 = (lab2 != 255).sum().double(); n3 = (lab3 != 255).sum().double()
+        # the two halves partition the valid pixels: weighted mean of the half losses == full loss
+        mix = (b.double() * n2 + c.double() * n3) / (n2 + n3)
+    assert abs(mix.item() - a.item()) <= 1e-5 * abs(a.item()), (a.item(), mix.item())
+    assert abs(b.item() - a.item()) > 0 or abs(c.item() - a.item()) > 0
+
+
+FULL_SHAPES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil      
+    (4, 256, 128, 256, 256, 3, 1, 2, 2),      # layer3 conv2
+    (4, 256, 128, 256, 1024, 1, 1, 0, 1),     # layer3 conv3
+    (4, 1024, 128, 256, 256, 1, 1, 0, 1),     # layer3 conv1
+    (4, 2048, 128, 256, 256, 3, 1, 12, 12),   # ASPP
+    (4, 64, 512, 1024, 128, 3, 1, 1, 1),      # stem
+    (4, 128, 256, 512, 128, 3, 2, 1, 1),      # layer2.0 conv2 (stride 2)
+    (4, 3, 1024, 2048, 64, 3, 2, 1, 1),       # first conv
+    (4, 512, 128, 256, 19, 1, 1, 0, 1),       # classifier
+]
+
+
+@pytest.mark.parametrize("shape", FULL_SHAPES)
+def test_config3_conv_power_of_two_homogeneity(cuda, shape):
+    from dcfp_amd import ops
+    N, Cin, H, W, Cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5).to(cuda)
+    y = ops.conv2d_fwd(x, w, None, s, p, d)
+    assert torch.equal(ops.conv2d_fwd(x * 2, w, None, s, p, d), y * 2)
+    assert torch.equal(ops.conv2d_fwd(x, w * 0.25, None, s, p, d), y * 0.25)
+    dy = torch.randn(y.shape, generator=g).to(cuda)
+    dx = ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d)
+    assert torch.equal(ops.conv2d_dgrad(dy * 4, w, tuple(x.shape), s, p, d), dx * 4)
+    seed = torch.randn(x.shape, generator=g).to(cuda)
+    acc = seed.clone()
+    ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d, out=acc, accumulate=True)
+    assert torch.equal(acc, seed + dx)
+    dw = ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, d)[0]
+    assert torch.equal(ops.conv2d_wgrad(dy * 0.5, x * 8, tuple(w.shape), s, p, d)[0], dw * 4)
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    # spot values against an fp64 dot product (64 random outputs of the forward)
+    idx = torch.randint(0, y.numel(), (64,), generator=g)
+    xd = torch.nn.functional.pad(x.double(), (p, p, p, p)); wd = w.double()
+    Ho, Wo = y.shape[2], y.shape[3]
+    for i in idx.tolist():
+        n, r = divmod(i, Cout * Ho * Wo); co, r = divmod(r, Ho * Wo); oy, ox = divmod(r, Wo)
+        patch = xd[n, :, oy * s: oy * s + d * (k - 1) + 1: d, ox * s: ox * s + d * (k - 1) + 1: d]
+        ref = (patch * wd[co]).sum().item()
+        assert abs(y.view(-1)[i].item() - ref) <= 1e-4 * max(1.0, abs(ref)), (i, y.view(-1)[i].item(), ref)
