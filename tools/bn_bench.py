@@ -41,7 +41,16 @@ def main():
             ("bwd_apply(x-mask)", 12 * n, lambda: ops.bn_bwd_apply(dy, x, None, mean, var, g, b, 1e-5, s1, s2, float(n // C), 2, False)),
             ("bwd_apply(y-mask,+res)", 20 * n, lambda: ops.bn_bwd_apply(dy, x, y, mean, var, g, b, 1e-5, s1, s2, float(n // C), 1, True)),
         ]
-        print(shape)
+        def fwd_pair():
+            m_, v_ = ops.bn_stats(x)
+            ops.bn_apply(x, m_, v_, g, b, 1e-5, None, True)
+
+        def bwd_pair():
+            a_, b_, _ = ops.bn_bwd_reduce(dy, x, None, mean, var, g, b, 1e-5, 2)
+            ops.bn_bwd_apply(dy, x, None, mean, var, g, b, 1e-5, a_, b_, float(n // C), 2, False)
+        # the sequences the step runs: the second kernel re-reads what the first just streamed
+        rows += [("stats -> apply", 12 * n, fwd_pair), ("bwd_reduce -> bwd_apply", 20 * n, bwd_pair)]
+        print(shape, "DCFP_BN_ORDER=" + os.environ.get("DCFP_BN_ORDER", "0"))
         for name, nbytes, fn in rows:
             ms = bench(fn)
             print(f"  {name:24s} {ms:7.3f} ms  {nbytes / ms / 1e6:7.0f} GB/s", flush=True)
