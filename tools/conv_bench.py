@@ -33,7 +33,9 @@ SHAPES = {
 
 
 def bench(fn, iters):
-    fn(); torch.cuda.synchronize()
+    for _ in range(max(3, iters)):      # the clocks take tens of ms to ramp after an idle gap
+        fn()
+    torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
