@@ -501,32 +501,36 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory");
         });
-        if constexpr (!MIXED) {
-            static_for<0, 4>([&](auto q_) {
-                constexpr int q = decltype(q_)::value;
-                const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 16 * q) * BK) * 4u);
-                const int hh = oh + bq_dh[q], ww = ow + 4 * gq + bq_dw[q];
-                const bool ok = hh >= 0 && hh < p.H && ww >= 0 && ww + 3 < p.W;
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 16 * q) * BK) * 4u);
+            const int hh = oh + bq_dh[q], ww = ow + 4 * gq + bq_dw[q];
+            const bool row_ok = hh >= 0 && hh < p.H;
+            const bool ok = row_ok && ww >= 0 && ww + 3 < p.W;
+            const unsigned bs_ = b_img;
+            const u32x4 bd = b_desc;
+            bool quads = true;
+            if constexpr (MIXED)      // a quad that straddles the image border: only on a row's first / last K-step
+                quads = __ballot(row_ok && !ok && ww > -4 && ww < p.W) == 0;
+            if (quads) {             // 16-byte copies; with a shifted tap the source is only 4/8-byte aligned
                 const unsigned bv = ok ? (unsigned)(bq_c[q] + hh * p.W + ww) * 4u : kOob;
-                const unsigned bs_ = b_img;
-                const u32x4 bd = b_desc;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                              :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
-            });
-        } else {
-            static_for<0, 16>([&](auto qe_) {
-                constexpr int qe = decltype(qe_)::value;
-                constexpr int e = qe & 3;
-                const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 4 * qe) * BK) * 4u);
-                const int hh = oh + bd_dh[qe], ww = ow + 4 * (gd ^ e) + (lane & 3) + bd_dw[qe];
-                const bool ok = hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
-                const unsigned bv = ok ? (unsigned)(bd_c[qe] + hh * p.W + ww) * 4u : kOob;
-                const unsigned bs_ = b_img;
-                const u32x4 bd = b_desc;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
-            });
-        }
+            } else if constexpr (MIXED) {
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    constexpr int qe = 4 * q + e;
+                    const unsigned le = lb + (unsigned)(4 * e * BK) * 4u;
+                    const int h1 = oh + bd_dh[qe], w1 = ow + 4 * (gd ^ e) + (lane & 3) + bd_dw[qe];
+                    const bool ok1 = h1 >= 0 && h1 < p.H && w1 >= 0 && w1 < p.W;
+                    const unsigned bv = ok1 ? (unsigned)(bd_c[qe] + h1 * p.W + w1) * 4u : kOob;
+                    const unsigned bs2 = bs_;
+                    const u32x4 bd2 = bd;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory");
+                });
+            }
+        });
         c_ow += BK;
         if (c_ow >= p.Wo) { c_ow = 0; if (++c_oh >= p.Ho) { c_oh = 0; ++c_im; } }
     };
@@ -688,10 +692,11 @@ int launch_cfg(const WgradParams& p, long long blocks, hipStream_t stream) {
 // shapes the LDS-DMA kernel takes: 256 x 256 tile, stride 1, output = input size, rows of 16 k pixels
 static bool wgrad_dma_ok(const DcfpConvDesc* d, int cfg) {
     static const bool on = [] { const char* e = getenv("DCFP_WGRAD_DMA"); return !e || atoi(e) != 0; }();   // =0: off
-    static const bool mixed_too = [] { const char* e = getenv("DCFP_WGRAD_DMA_MIXED"); return e && atoi(e) != 0; }();
+    static const bool mixed_too = [] { const char* e = getenv("DCFP_WGRAD_DMA_MIXED"); return !e || atoi(e) != 0; }();   // =0: off
     const bool mixed = d->KH == 3 && ((d->pad | d->dil) & 3) != 0;
-    // same-box A/B: +17 % where every tap keeps quads aligned (1x1, dilation 4/8/12/...), -1 % with the
-    // dword copies that dilation 1/2 need - those stay on the register-staged kernel
+    // same-box A/B against the register-staged kernel: +17 % where every tap keeps quads aligned (1x1,
+    // dilation 4/8/12/...); +7 % for dilation 1/2 (16-byte copies from the 4/8-byte aligned shifted source,
+    // dword copies only on the K-steps whose quads straddle the image border; -1 % with dword copies throughout)
     return on && cfg == 0 && d->stride == 1 && d->Hout == d->H && d->Wout == d->W && d->W % 16 == 0 &&
            (!mixed || mixed_too);
 }

@@ -88,6 +88,8 @@ def test_large_conv_parity(cuda, mode):
     fwd_kernel, wgrad_kernel = ("igemm3_kernel", "wgrad3_kernel") if mode == "bf16x3" else \
         ("igemm2_", "wgrad2_kernel")     # igemm2_kernel<...> or the LDS-DMA igemm2_dma_kernel<1>
     assert sum(rec["kernels"][2].startswith(wgrad_kernel) for rec in res) >= 2, res
+    if mode == "f32":   # the +-1 tap case goes through the LDS-DMA wgrad with shifted 16-byte copies
+        assert res[3]["kernels"][2] == "wgrad_dma_kernel<9,true>", res[3]["kernels"]
     for rec in res:
         N, Cin, H, W, Cout, k, p, d = rec["case"]
         assert rec["kernels"][0].startswith(fwd_kernel), rec
