@@ -39,6 +39,7 @@ struct Igemm2Params {
     int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
     int sn, sd, off0, offstep;
     int accumulate, vec_store;
+    int tile2d;         // igemm2_dma_kernel<9, true>: 0, or log2(columns) of a 2-D pixel tile (8 rows x 32 or 16 x 16)
     float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
 };
 
@@ -500,7 +501,20 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     const int mt = local >> 3;
     if (nt >= p.tiles_n_total) return;
     const int img = nt / p.tiles_per_img;
-    const int p0 = (nt - img * p.tiles_per_img) * BN;
+    const int ti = nt - img * p.tiles_per_img;
+    // Pixel tile: 256 consecutive pixels, or (tile2d, shifted taps only) 8 rows x 32 columns, so that only the
+    // tiles on the image's left / right edge see quads that straddle the border and all others can copy 16
+    // bytes per lane from the shifted source.  loc -> offset of tile pixel `loc` from the tile's first pixel.
+    const bool t2d = MIXED && p.tile2d != 0;
+    const int tsh = p.tile2d, tcols = 1 << tsh;        // tile2d = log2(columns per tile row)
+    int p0 = ti * BN, t_ow0 = 0;
+    if (t2d) {
+        const int wt = p.Wi >> tsh;
+        const int th = ti / wt;
+        t_ow0 = (ti - th * wt) << tsh;
+        p0 = th * (BN >> tsh) * p.Wi + t_ow0;
+    }
+    auto pixoff = [&](int loc) { return t2d ? (loc >> tsh) * p.Wi + (loc & (tcols - 1)) : loc; };
     const int m0 = mt * BM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -519,13 +533,13 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     int q_oh, q_ow, s_oh[4], s_ow[4];
     bool q_in, s_in[4] = {true, true, true, true};     // pixels past P (last tile of an image) copy zeros
     {
-        const int pp = p0 + 4 * lane;
+        const int pp = p0 + pixoff(4 * lane);
         q_in = pp < p.P;                                // P % 4 == 0: a quad is inside or outside as a whole
         q_oh = pp / p.Wo; q_ow = pp - q_oh * p.Wo;
         if constexpr (MIXED) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ps = p0 + 64 * e + lane;
+                const int ps = p0 + pixoff(64 * e + lane);
                 s_in[e] = ps < p.P;
                 s_oh[e] = ps / p.Wo; s_ow[e] = ps - s_oh[e] * p.Wo;
             }
@@ -540,7 +554,7 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         const int kh = (TAPS == 9) ? t / 3 : 0;
         const int kw = (TAPS == 9) ? t - kh * 3 : 0;
         const int offh = p.off0 + kh * p.offstep, offw = p.off0 + kw * p.offstep;
-        tap_quads = !MIXED || (offw & 3) == 0;
+        tap_quads = !MIXED || (offw & 3) == 0 || (t2d && t_ow0 + offw >= 0 && t_ow0 + tcols - 1 + offw < p.Wi);
         {
             const int hh = q_oh + offh, ww = q_ow + offw;
             const bool ok = q_in && hh >= 0 && hh < p.Hi && ww >= 0 && ww + 3 < p.Wi;
@@ -643,8 +657,8 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         retire();
     }
     float* o_img = p.out + (long long)img * p.out_nstride;
-    if (m0 + BM > p.M || p0 + BN > p.P) {     // edge tile (block-uniform): predicated stores
-        int pix = p0 + wn * (TN * 32) + TN * l31;
+    if (m0 + BM > p.M || (!t2d && p0 + BN > p.P)) {     // edge tile (block-uniform): predicated stores
+        int pix = p0 + pixoff(wn * (TN * 32) + TN * l31);
         asm volatile("" : "+v"(pix));
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -663,7 +677,7 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     }
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         o_img + (long long)m0 * p.P + p0, 0, 0x7ffffffcu, 0x00020000);
-    unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
+    unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + pixoff(wn * (TN * 32) + TN * l31)) * 4u;
     asm volatile("" : "+v"(voff));
     const unsigned P4 = (unsigned)p.P * 4u;
     static_for<0, TM>([&](auto i_) {
@@ -810,6 +824,11 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
+    {
+        static const int t2d = [] { const char* e = getenv("DCFP_IGEMM_2D"); return e ? atoi(e) : 5; }();   // 0: off; 4 / 5: 16 / 32 columns
+        const bool fits = (t2d == 4 || t2d == 5) && Hi % (256 >> t2d) == 0 && Wi % (1 << t2d) == 0;
+        p.tile2d = (fits && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
+    }
     p.tiles_per_img = (p.P + c.bn - 1) / c.bn;
     p.tiles_n_total = p.tiles_per_img * N;
     p.tiles_m = p.Mpad / c.bm;
