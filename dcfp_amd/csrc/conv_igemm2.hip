@@ -675,6 +675,49 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         }
         return;
     }
+    if constexpr (!ACC) {
+        if (p.stat_part) {
+            // BatchNorm statistics of this tile's rows (mean, M2 over the wave's 128 pixels, Chan-merged by
+            // dcfp_bn_stats_from_partials_f32).  The cross-lane part goes through the now idle LDS: every lane
+            // leaves (sum, M2) of its 4 pixels per row, then lane L merges the 32 partials of one row - 128
+            // LDS operations per wave instead of the 640 swizzles of a butterfly per row.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2* st = reinterpret_cast<f32x2*>(smem) + wid * (64 * 33);
+            float* sp = p.stat_part + ((long long)(nt * WN + wn) * p.M + m0 + wm * (TM * 32)) * 2;
+            static_for<0, 2>([&](auto h_) {
+                constexpr int half = decltype(h_)::value;
+                static_for<0, 2>([&](auto ii_) {
+                    constexpr int ii = decltype(ii_)::value;
+                    constexpr int i = 2 * half + ii;
+                    static_for<0, 16>([&](auto r_) {
+                        constexpr int r = decltype(r_)::value;
+                        const float a0 = acc[i][0][r], a1 = acc[i][1][r], a2 = acc[i][2][r], a3 = acc[i][3][r];
+                        const float s4 = (a0 + a1) + (a2 + a3);
+                        const float mu = 0.25f * s4;
+                        const float d0 = a0 - mu, d1 = a1 - mu, d2 = a2 - mu, d3 = a3 - mu;
+                        f32x2 v = {s4, (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)};
+                        st[(lhi * 32 + ii * 16 + r) * 33 + l31] = v;
+                    });
+                });
+                float sv[32], S = 0.f, M2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const f32x2 v = st[lane * 33 + k];
+                    sv[k] = v.x; S += v.x; M2 += v.y;
+                }
+                const float mean = S * (1.0f / 128.0f);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const float d = 0.25f * sv[k] - mean;
+                    M2 += 4.0f * d * d;
+                }
+                const int rr = lane & 15;
+                const int row = 16 * (lane >> 5) + 4 * (rr & 3) + 32 * (rr >> 2) + 2 * half + ((lane >> 4) & 1);
+                sp[row * 2] = mean;
+                sp[row * 2 + 1] = M2;
+            });
+        }
+    }
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         o_img + (long long)m0 * p.P + p0, 0, 0x7ffffffcu, 0x00020000);
     unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + pixoff(wn * (TN * 32) + TN * l31)) * 4u;
@@ -847,10 +890,11 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                            Ck, p.CkP, M, p.Mpad, sAm, sAc);
     }
     if (dcfp_igemm2_dma_shape(T, M, Ck, p.P, px, sn, sd, off0, Hi * Wi, Wo) && p.vec_store && !bias && !scale &&
-        !relu && !stat_part) {
+        !relu && !(stat_part && accumulate)) {
         const long long groups = ((long long)p.tiles_n_total + 7) / 8;
         const long long blocks = groups * 8 * p.tiles_m;
-        const size_t lds = (size_t)2 * BK * 512 * sizeof(float);
+        // 64 KB of operand buffers; the statistics epilogue re-uses them as 4 x [64 rows][33] (sum, M2) pairs
+        const size_t lds = stat_part ? (size_t)4 * 64 * 33 * 8 : (size_t)2 * BK * 512 * sizeof(float);
         auto launch = [&](auto kern) -> int {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -105,10 +105,10 @@ def _desc(xshape, wshape, stride, pad, dil):
 
 
 # ------------------------------------------------------------------ conv2d
-# Opt-in (DCFP_FUSED_BN_STATS=1): the Bottleneck convs emit the batch statistics of their output for
-# the BatchNorm behind them.  Measured neutral on MI355X (BN -6 ms/step, conv epilogues +5 ms/step:
-# 640 cross-lane exchanges per wave and tile), so the separate bn_stats pass stays the default.
-FUSE_BN_STATS = os.environ.get("DCFP_FUSED_BN_STATS", "") not in ("", "0")
+# The Bottleneck convs emit the batch statistics of their output for the BatchNorm behind them (no
+# 4 B/element stats pass): BN -6 ms/step, conv epilogues +1 ms/step since the LDS-DMA kernels merge the
+# per-lane partials through LDS instead of 640 swizzles per wave and tile.  DCFP_FUSED_BN_STATS=0: off.
+FUSE_BN_STATS = os.environ.get("DCFP_FUSED_BN_STATS", "1") not in ("0",)
 # The residual BatchNorm of a Bottleneck keeps its ReLU mask as one bit per element for the backward
 # (instead of two re-reads of the 4-byte block output); DCFP_BN_RELU_BITMASK=0 switches it off.
 BN_RELU_BITMASK = os.environ.get("DCFP_BN_RELU_BITMASK", "1") not in ("0",)

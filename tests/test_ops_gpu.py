@@ -274,7 +274,7 @@ def test_syncbn_combine_kernel(cuda, world, C):
     assert abs(out[2 * C].item() - tot.item()) < 1e-3
 
 
-@pytest.mark.parametrize("Cout,k", [(256, 1), (128, 3), (64, 1), (512, 1)])
+@pytest.mark.parametrize("Cout,k", [(256, 1), (128, 3), (64, 1), (512, 1), (256, 3)])
 def test_conv_fused_bn_stats(cuda, Cout, k):
     """BatchNorm batch statistics emitted by the conv epilogue (Welford partials over 128-pixel
     runs, merged in fp64) against the statistics of the conv output itself and bn_stats."""
