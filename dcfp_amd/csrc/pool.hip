@@ -73,6 +73,42 @@ maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict_
     }
 }
 
+// Same gather, four input columns per thread and no integer divisions: block = one input row segment.
+// Columns w0..w0+3 (w0 % 4 == 0) lie in the windows ow = w0/2 .. w0/2+2, row h in oh = h/2 .. (h+1)/2;
+// contributions are added in the same (oh, ow) order as above, so both kernels agree bit for bit.
+__global__ void __launch_bounds__(kThreads)
+maxpool3x3s2_bwd_vec4_kernel(const float* __restrict__ dy, const int32_t* __restrict__ argmax,
+                             float* __restrict__ dx, int H, int W, int Hout, int Wout, int segs) {
+    const long long rowid = blockIdx.x / segs;              // plane * H + h
+    const int seg = blockIdx.x - (int)(rowid * segs);
+    const long long plane = rowid / H;
+    const int h = (int)(rowid - plane * H);
+    const int w0 = 4 * (seg * kThreads + threadIdx.x);
+    if (w0 >= W) return;
+    const float* dyp = dy + plane * (long long)Hout * Wout;
+    const int32_t* ap = argmax + plane * (long long)Hout * Wout;
+    const int oh_lo = h / 2, oh_hi = (h + 1) / 2, c0 = w0 / 2;
+    const int me = h * W + w0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        if (oh >= Hout) continue;
+        const int base = oh * Wout + c0;
+        const int i0 = ap[base];
+        const float g0 = dyp[base];
+        int i1 = -1, i2 = -1;
+        float g1 = 0.f, g2 = 0.f;
+        if (c0 + 1 < Wout) { i1 = ap[base + 1]; g1 = dyp[base + 1]; }
+        if (c0 + 2 < Wout) { i2 = ap[base + 2]; g2 = dyp[base + 2]; }
+        if (i0 == me) a0 += g0;
+        if (i0 == me + 1) a1 += g0;
+        if (i1 == me + 1) a1 += g1;
+        if (i1 == me + 2) a2 += g1;
+        if (i1 == me + 3) a3 += g1;
+        if (i2 == me + 3) a3 += g2;
+    }
+    *reinterpret_cast<float4*>(dx + rowid * W + w0) = make_float4(a0, a1, a2, a3);
+}
+
 // y[row] = scale * sum_i x[row, i]; one block per (n,c) row.
 __global__ void __launch_bounds__(kThreads)
 rowsum_kernel(const float* __restrict__ x, long long x_nstride, float* __restrict__ y, float scale,
@@ -189,8 +225,14 @@ extern "C" int dcfp_maxpool3x3s2_bwd_f32(const float* dy, const int32_t* argmax,
     if (!dy || !dx || !argmax || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DCFP_E_BADDESC;
     if (Hout != (H + 2 - 3) / 2 + 1 || Wout != (W + 2 - 3) / 2 + 1) return DCFP_E_BADDESC;
     const long long total = (long long)N * C * H * W;
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(stream_grid(total)), dim3(kThreads), 0,
-                       dcfp_s(stream), dy, argmax, dx, total, H, W, Hout, Wout);
+    const long long rows = (long long)N * C * H;
+    const int segs = (W / 4 + kThreads - 1) / kThreads;
+    if (W % 4 == 0 && dcfp_aligned16(dx) && rows * segs <= 0x7fffffffLL)
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_vec4_kernel, dim3((unsigned)(rows * segs)), dim3(kThreads), 0,
+                           dcfp_s(stream), dy, argmax, dx, H, W, Hout, Wout, segs);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), dy, argmax, dx, total, H, W, Hout, Wout);
     DCFP_RETURN_LAUNCH();
 }
 

@@ -89,7 +89,8 @@ def test_random_upsample_ce(cuda, case):
     assert rel(zg.grad, zr.grad) < 3e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 7, 9), (2, 64, 33, 47), (3, 17, 2, 2), (1, 5, 64, 1)])
+@pytest.mark.parametrize("shape", [(1, 3, 7, 9), (2, 64, 33, 47), (3, 17, 2, 2), (1, 5, 64, 1),
+                                   (2, 5, 9, 12), (1, 3, 6, 1028), (2, 4, 16, 4)])   # W % 4 == 0: the 4-column backward
 def test_random_maxpool(cuda, shape):
     from dcfp_amd import ops
     g = torch.Generator().manual_seed(3)
