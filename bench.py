@@ -167,9 +167,75 @@ def roofline_from_profile(recs, images_per_step, step_s):
     return roof, extra
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, worker=None, device_count=None, poll_s=0.2):
+    """`python bench.py --gpus N` without a launcher: start N CHILD worker processes, one per GPU
+    (scripts/cs/pretrain.sh:31 + engine.py:38-46: one process per device, env:// rendezvous), wait
+    for them and forward rank 0's JSON line.  Runs before anything in this process touches the GPU
+    (torch.cuda.device_count() does not initialise it), never exec()s, and fails non-zero when
+    fewer than N devices are visible instead of silently measuring one."""
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) visible; refusing to report a "
+              f"{have}-GPU number as an {n}-GPU result", file=sys.stderr)
+        return 2
+    worker = worker or [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(worker + list(argv), env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # drain rank 0's stdout on a thread so a chatty worker cannot fill the pipe
+    import threading
+    lines = []
+    t = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    t.start()
+    rc = 0
+    pending = set(range(n))
+    while pending and rc == 0:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
+        time.sleep(poll_s)
+    for r in pending:          # a rank failed: stop exactly the children started here
+        procs[r].terminate()
+    for r in pending:
+        try:
+            procs[r].wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    t.join(timeout=30)
+    if rc:
+        return rc
+    recs = [l for l in lines if l.startswith("{")]
+    if not recs:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    rec = json.loads(recs[-1])
+    if rec.get("n_gpus") != n or rec.get("rccl_ranks") != n:
+        print(f"bench.py: asked for {n} ranks, rank 0 reports n_gpus={rec.get('n_gpus')} "
+              f"rccl_ranks={rec.get('rccl_ranks')}", file=sys.stderr)
+        return 1
+    print(recs[-1].rstrip("\n"))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE or 1")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--backbone", default="resnet101")
@@ -186,7 +252,11 @@ def main():
                     help="wrap in SyncBN+DDP and run the collectives even at world size 1 (rehearsal)")
     args, _ = ap.parse_known_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent: no GPU call before this point
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} contradicts WORLD_SIZE={world} set by the launcher")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -297,13 +367,16 @@ def main():
 
     if rank == 0:
         out = {"metric": "training images/sec at 1024x2048 DeepLabv3-R101", "value": value, "unit": "images/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+               "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if os.environ.get("DCFP_CONV_MATH", "") in ("", "f32") else "f32 via bf16x3 split",
                "data": "synthetic",
                "config": {"workload": ("PRUNED (" + args.channel_cfg + ") " if args.channel_cfg else "") +
                                       f"DeepLabv3-{args.backbone}+ASPP os8, {args.batch}x3x{H}x{W} per GPU, "
-                                      "CE+0.4*deepsup CE (fused upsample), SyncBN+DDP, EIC step, SGD m0.9 wd5e-4",
+                                      "CE+0.4*deepsup CE (fused upsample), " +
+                                      ("SyncBN + gradient all-reduce over RCCL, " if ddp else "") +
+                                      "EIC step, SGD m0.9 wd5e-4",
                           "global_batch": global_batch, "parallelism": f"dp{world}"},
                "final_loss": last, "peak_mem_GiB": peak_mem,
                "sgd_table_rebuilds": sgd_rebuilds,
