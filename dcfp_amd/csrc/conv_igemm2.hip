@@ -593,11 +593,11 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
             const unsigned av = a_voff[q], as_ = a_s, bs_ = b_s;
             const u32x4 ad = a_desc, bd = b_desc;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory");
+                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory", "m0");
             if (tap_quads) {
                 const unsigned bv = boff4 + b_row[q] + b_cb;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
+                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
             } else if constexpr (MIXED) {
                 static_for<0, 4>([&](auto e_) {
                     constexpr int e = decltype(e_)::value;
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
                     const unsigned le = lb + 256u * e, bs2 = bs_;
                     const u32x4 bd2 = bd;      // (asm operands must be locals of the innermost lambda)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory");
+                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory", "m0");
                 });
             }
         });

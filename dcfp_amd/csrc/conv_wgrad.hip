@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
             const unsigned av = a_voff[q], as_ = a_s;
             const u32x4 ad = a_desc;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory");
+                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory", "m0");
         });
         static_for<0, 4>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
             if (quads) {             // 16-byte copies; with a shifted tap the source is only 4/8-byte aligned
                 const unsigned bv = ok ? (unsigned)(bq_c[q] + hh * p.W + ww) * 4u : kOob;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory");
+                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
             } else if constexpr (MIXED) {
                 static_for<0, 4>([&](auto e_) {
                     constexpr int e = decltype(e_)::value;
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
                     const unsigned bs2 = bs_;
                     const u32x4 bd2 = bd;
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory");
+                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory", "m0");
                 });
             }
         });

@@ -31,6 +31,8 @@ def _bn_args(m):
     if isinstance(m, nn.SyncBatchNorm) and training:
         sync = m.process_group if m.process_group is not None else True
     momentum = m.momentum
+    if training:
+        m._dcfp_fold = None     # running statistics are about to change through raw pointers
     if training and m.track_running_stats and m.num_batches_tracked is not None:
         m.num_batches_tracked.add_(1)
         if momentum is None:
@@ -47,9 +49,12 @@ def bn_act(m, x, relu=False, residual=None):
 
 
 def _fold(bn):
-    """(scale, shift) of an eval-mode BatchNorm, cached until its tensors change."""
+    """(scale, shift) of an eval-mode BatchNorm, cached until its tensors change.  The HIP optimizer
+    and the running-statistics kernel write through raw pointers (no `_version` bump), so the key
+    also carries ops.WEIGHT_EPOCH (bumped by every FusedSGD.step / load_state_dict) and a training
+    forward drops the cache (_bn_args)."""
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+           bn.weight.data_ptr(), bn.running_mean.data_ptr(), ops.WEIGHT_EPOCH[0])
     cached = getattr(bn, "_dcfp_fold", None)
     if cached is None or cached[0] != key:
         with torch.no_grad():

@@ -14,6 +14,10 @@ from . import _lib
 from ._lib import ConvDesc, check
 
 _ws_cache = {}
+# Bumped whenever parameters are rewritten through raw pointers (FusedSGD.step, load_state_dict):
+# caches derived from weights (folded eval-mode BN, permuted conv weights) key on it because
+# torch's per-tensor `_version` does not see those writes.
+WEIGHT_EPOCH = [0]
 
 # ---- optional per-launch timing (bench.py's roofline leg): when a list is installed, every
 # conv / BN C-ABI call is bracketed by events on the stream it is launched on.

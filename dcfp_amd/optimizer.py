@@ -100,6 +100,8 @@ class FusedSGD(torch.optim.Optimizer):
             check(L.dcfp_sgd_momentum_f32(C.c_void_p(table.data_ptr()), n, chunks, float(group["lr"]),
                                           float(group["momentum"]), first, stream), "sgd_momentum")
             group["_stepped"] = True
+        from . import ops
+        ops.WEIGHT_EPOCH[0] += 1
         return loss
 
 

@@ -8,8 +8,13 @@
  *
  * Conventions
  *   - every buffer (including workspace) is owned by the caller; the library
- *     allocates nothing and keeps no mutable global state; all launches are
+ *     allocates nothing and keeps no state between calls; all launches are
  *     stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default).
+ *     The only process-wide state is a set of tuning switches read ONCE from the
+ *     environment into function-local statics on first use (DCFP_CONV_MATH,
+ *     DCFP_IGEMM_DMA, DCFP_IGEMM_DMA9, DCFP_IGEMM_2D, DCFP_IGEMM_BK32, DCFP_WGRAD_DMA, ...:
+ *     kernel-selection A/B knobs, results are identical up to the documented fp32
+ *     tolerances); changing them after the first call has no effect.
  *   - tensors are fp32, NCHW, dense unless a *_nstride (batch stride, in elements)
  *     argument says otherwise.
  *   - return value: 0 ok; <0 bad descriptor / unsupported shape (DCFP_E_*);

@@ -168,10 +168,16 @@ def eic_trajectory():
     print("wrote eic_trajectory", rec["names"])
 
 
-def masks_and_surgery():
-    for gp in (0.5, 0.7):
+PRUNE_CASES = [("v3r50", "deeplabv3", "resnet50", True, 0.5), ("v3r50", "deeplabv3", "resnet50", True, 0.7),
+               ("v3r101", "deeplabv3", "resnet101", True, 0.5), ("simple_r50", "simple", "resnet50", False, 0.5)]
+
+
+def masks_and_surgery(only=None):
+    for tag, model, backbone, align, gp in PRUNE_CASES:
+        if only is not None and tag not in only:
+            continue
         torch.manual_seed(0)
-        m = build_ref("deeplabv3", "resnet50", True, torch.float32)
+        m = build_ref(model, backbone, align, torch.float32)
         m.criterion = None
         eic = synthetic_scores(m)
         score_path = "/tmp/_golden_score.pth"
@@ -199,7 +205,7 @@ def masks_and_surgery():
         rec["pruned_sum"] = np.array([float(v.double().sum()) for v in sd.values()])
         rec["pruned_abs"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
         # slim model rebuilt by init_pruned_model + forward sanity (prune.py:100-110)
-        slim = build_ref("deeplabv3", "resnet50", True, torch.float32)
+        slim = build_ref(model, backbone, align, torch.float32)
         slim.criterion = None
         pruners.init_pruned_model(slim, channel_cfg)
         rec["slim_shapes"] = np.array([str(tuple(v.shape)) for v in slim.state_dict().values()])
@@ -208,8 +214,8 @@ def masks_and_surgery():
         with torch.no_grad():
             y = slim(fill.closed_form_input(2, 33, 33), None, deepsup=True)
         rec["slim_logits"] = y[0].numpy()
-        np.savez_compressed(os.path.join(OUT, f"prune_v3r50_gp{int(gp * 100)}.npz"), **rec)
-        print("wrote prune golden gp", gp, "thresh", rec["thresh"],
+        np.savez_compressed(os.path.join(OUT, f"prune_{tag}_gp{int(gp * 100)}.npz"), **rec)
+        print("wrote prune golden", tag, "gp", gp, "thresh", rec["thresh"],
               "kept", sum(int(c.get("out_channels", 0)) for c in channel_cfg.values()))
 
 
@@ -315,6 +321,8 @@ if __name__ == "__main__":
         whole_model("v3_r101_2x65x65", "deeplabv3", "resnet101", 2, 65, 65, True)
     if "prune" in which:
         masks_and_surgery()
+    if "prune_new" in which:    # the R101 / `simple` cases added in round 2 (leaves the R50 fixtures untouched)
+        masks_and_surgery(only=("v3r101", "simple_r50"))
     if "flops" in which:
         flops_golden()
     if "gsrl" in which:

@@ -180,3 +180,63 @@ def test_config3_conv_power_of_two_homogeneity(cuda, shape):
         patch = xd[n, :, oy * s: oy * s + d * (k - 1) + 1: d, ox * s: ox * s + d * (k - 1) + 1: d]
         ref = (patch * wd[co]).sum().item()
         assert abs(y.view(-1)[i].item() - ref) <= 1e-4 * max(1.0, abs(ref)), (i, y.view(-1)[i].item(), ref)
+
+
+# the exact config-3 launch geometries of dgrad / wgrad (split-K factor, 8 x 32 pixel tiles at W = 256,
+# stride-2 dgrad) against fp64 on a channel slice; expected kernel family per pass as a routing check
+SLICE_SHAPES = [
+    ((4, 256, 128, 256, 256, 3, 1, 2, 2), ("igemm2_dma_kernel<9,true>", "wgrad_dma_kernel<9,true>")),     # layer3 conv2
+    ((4, 256, 128, 256, 1024, 1, 1, 0, 1), ("igemm2_dma_kernel<1,false>", "wgrad_dma_kernel<1,false>")),  # layer3 conv3
+    ((4, 1024, 128, 256, 256, 1, 1, 0, 1), ("igemm2_dma_kernel<1,false>", "wgrad_dma_kernel<1,false>")),  # layer3 conv1
+    ((4, 2048, 128, 256, 256, 3, 1, 12, 12), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # ASPP
+    ((4, 1024, 128, 256, 512, 3, 1, 1, 1), ("igemm2_dma_kernel<9,true>", "wgrad_dma_kernel<9,true>")),    # conv_deepsup.0
+    ((4, 64, 512, 1024, 128, 3, 1, 1, 1), (None, None)),                                                  # stem
+    ((4, 128, 256, 512, 128, 3, 2, 1, 1), (None, None)),                                                  # layer2.0 conv2 (stride 2)
+    ((4, 256, 256, 512, 512, 1, 2, 0, 1), (None, None)),                                                  # layer2.0 downsample (stride 2)
+]
+
+
+@pytest.mark.parametrize("shape,kernels", SLICE_SHAPES)
+def test_config3_dgrad_wgrad_vs_fp64_slice(cuda, shape, kernels):
+    import math
+    import torch.nn.functional as F
+    from dcfp_amd import ops, _lib
+    N, Cin, H, W, Cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = (torch.relu(x) + 0.05 * x).to(cuda)                    # post-ReLU-like statistics
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).to(cuda)
+    desc = ops._desc(x.shape, w.shape, s, p, d)
+    for want, which in zip(kernels, (_lib.CONV_DGRAD, _lib.CONV_WGRAD)):
+        if want is not None:
+            assert ops.conv_kernel_name(desc, which) == want, (ops.conv_kernel_name(desc, which), want)
+    Ho, Wo = desc.Hout, desc.Wout
+    dy = (torch.randn(N, Cout, Ho, Wo, generator=g) * 1e-2).to(cuda)
+    dx = ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d)
+    seed = torch.randn(x.shape, generator=g).to(cuda)
+    dxa = seed.clone()
+    ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d, out=dxa, accumulate=True)
+    dw = ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, d)[0]
+    torch.cuda.synchronize()
+    # fp64 reference for a slice of input channels: dx[:, ci] and dw[:, ci] need every output channel of
+    # dy but only w[:, ci] / x[:, ci] (last channels: includes a ragged last tile where there is one)
+    nci = min(Cin, 16)
+    ci = slice(Cin - nci, Cin)
+    try:
+        x64 = x[:, ci].double().requires_grad_(True)
+        w64 = w[:, ci].double().requires_grad_(True)
+        F.conv2d(x64, w64, None, s, p, d).backward(dy.double())
+        rdx, rdw = x64.grad, w64.grad
+    except RuntimeError:                                        # no fp64 conv on the device: CPU
+        x64 = x[:, ci].double().cpu().requires_grad_(True)
+        w64 = w[:, ci].double().cpu().requires_grad_(True)
+        F.conv2d(x64, w64, None, s, p, d).backward(dy.double().cpu())
+        rdx, rdw = x64.grad.to(cuda), w64.grad.to(cuda)
+
+    def rel(a, b):
+        return ((a.double() - b).norm() / b.norm()).item()
+    Kd = Cout * k * k                                           # dgrad reduction length
+    tol = 3e-6 * max(1.0, math.sqrt(Kd) / 8)
+    assert rel(dx[:, ci], rdx) < max(tol, 1e-5), rel(dx[:, ci], rdx)
+    assert rel(dxa[:, ci], rdx + seed[:, ci].double()) < max(tol, 1e-5)
+    assert rel(dw[:, ci], rdw) < 2e-5, rel(dw[:, ci], rdw)      # N*Ho*Wo-long reduction, split-K in a fixed order

@@ -71,7 +71,8 @@ def test_forward_backward_vs_reference_golden(cuda, tag, model_name, backbone):
         r64, r32 = g[what + "64"], g[what + "32"]
         rel = np.linalg.norm(mine - r64) / np.linalg.norm(r64)
         ref_rel = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
-        assert rel <= max(5e-2, 3 * ref_rel), (what, rel, ref_rel)
+        # bounded by the reference's own fp32-vs-fp64 noise only (no fixed 5e-2 floor)
+        assert rel <= max(1e-3, 3 * ref_rel), (what, rel, ref_rel)
 
     # every parameter gradient through its L2 norm (fixture holds norms for all ~160-310 tensors)
     pn = g["param_names"].tolist()
@@ -80,12 +81,27 @@ def test_forward_backward_vs_reference_golden(cuda, tag, model_name, backbone):
     l64, l32 = g["grad_l2:64"], g["grad_l2:32"]
     rel = np.abs(mine - l64) / (np.abs(l64) + 1e-12)
     ref_rel = np.abs(l32 - l64) / (np.abs(l64) + 1e-12)
-    assert (rel <= np.maximum(5e-2, 3 * ref_rel)).all(), [(pn[i], rel[i], ref_rel[i]) for i in np.argsort(-rel)[:5]]
+    # noise level of the reference itself: a tensor whose own fp32 error happens to be tiny is held to
+    # the 90th percentile of the reference's per-tensor errors, not to a fixed floor
+    noise = float(np.quantile(ref_rel, 0.9))
+    bound = np.maximum(1e-3, 3 * np.maximum(ref_rel, noise))
+    assert (rel <= bound).all(), [(pn[i], rel[i], ref_rel[i]) for i in np.argsort(-rel / bound)[:5]]
+    # ... and through a fixed-cosine projection, which (unlike a norm) sees permuted / transposed gradients:
+    # a random error of relative size e moves the projection by ~ e * |g| / sqrt(2)
+    proj = np.array([float((params[k].grad.double().reshape(-1) *
+                            torch.cos(0.37 * torch.arange(params[k].numel(), dtype=torch.float64, device=cuda))).sum())
+                     for k in pn])
+    p64, p32 = g["grad_proj:64"], g["grad_proj:32"]
+    perr = np.abs(proj - p64) / (np.abs(l64) + 1e-12)
+    pref = np.abs(p32 - p64) / (np.abs(l64) + 1e-12)
+    pnoise = float(np.quantile(pref, 0.9))
+    pbound = np.maximum(1e-3, 3 * np.maximum(pref, pnoise))
+    assert (perr <= pbound).all(), [(pn[i], perr[i], pref[i]) for i in np.argsort(-perr / pbound)[:5]]
     for key in ("backbone.conv1.0", "backbone.layer1.0.conv1", "backbone.layer2.0.conv2", "last_conv.6"):
         a = params[key + ".weight"].grad.double().cpu().numpy(); b = g[f"wgrad:{key}:64"]
         rel = np.linalg.norm(a - b) / np.linalg.norm(b)
         ref_rel = np.linalg.norm(g[f"wgrad:{key}:32"] - b) / np.linalg.norm(b)
-        assert rel <= max(5e-2, 3 * ref_rel), (key, rel, ref_rel)
+        assert rel <= max(1e-3, 3 * ref_rel), (key, rel, ref_rel)
     sd = m.state_dict()
     assert np.abs(sd["backbone.bn1.running_mean"].cpu().numpy() - g["rm:backbone.bn1:64"]).max() < 1e-5
     assert np.abs(sd["backbone.bn1.running_var"].cpu().numpy() - g["rv:backbone.bn1:64"]).max() < 1e-5
@@ -279,3 +295,57 @@ def test_inference_path_vs_oracle(cuda):
     assert np.array_equal(cm, ref_cm.astype(np.int64))
     miou, _ = ev.mean_iou(torch.from_numpy(cm))
     assert abs(miou - evalmetrics.mean_iou(ref_cm)[0]) < 1e-12
+
+
+def _grads(m, x, lab):
+    for p in m.parameters():
+        p.grad = None
+    loss = m(x, lab, deepsup=True)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+def test_fused_bottleneck_matches_unfused(cuda):
+    """ops.BottleneckFn (one autograd node per residual block, conv1's dgrad accumulated into the
+    residual gradient, 1-bit ReLU mask) against the op-level Functions on the same weights: the same
+    kernels in the same order, so every gradient must agree far below the whole-model noise floor."""
+    from dcfp_amd.networks import _exec
+    x = fill.closed_form_input(2, 65, 97).to(cuda); lab = fill.closed_form_labels(2, 65, 97).to(cuda)
+    res = []
+    for fuse in (True, False):
+        _exec.FUSE_BLOCKS = fuse
+        try:
+            res.append(_grads(build("deeplabv3", "resnet50", True, cuda), x, lab))
+        finally:
+            _exec.FUSE_BLOCKS = True
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= 1e-6 * abs(l1)
+    worst = max(((g0[k] - g1[k]).norm() / (g1[k].norm() + 1e-30)).item() for k in g0)
+    assert worst <= 1e-5, worst
+
+
+def test_eval_after_training_step_refolds_bn(cuda):
+    """eval -> train step -> eval in one process: the folded eval-mode BN (cached per module) must be
+    rebuilt after FusedSGD / the running-statistics kernel rewrote its inputs through raw pointers."""
+    from dcfp_amd import optimizer as opt
+    m = build("deeplabv3", "resnet50", True, cuda)
+    x = fill.closed_form_input(2, 65, 65).to(cuda); lab = fill.closed_form_labels(2, 65, 65).to(cuda)
+
+    def eval_logits(folded):
+        m.eval()
+        with (torch.no_grad() if folded else torch.enable_grad()):
+            return m(x, None, deepsup=True)[0].detach()
+    a0 = eval_logits(True)
+
+    class A:
+        no_decay = None; optim = "sgd"; momentum = 0.9; learning_rate = 1e-2; weight_decay = 5e-4
+    optimizer = opt.build_optimizer(A, m)
+    m.train()
+    optimizer.zero_grad()
+    m(x, lab, deepsup=True)["loss"].backward()
+    optimizer.step()
+    a1, b1 = eval_logits(True), eval_logits(False)
+    scale = b1.abs().max().item()
+    assert (a1 - b1).abs().max().item() <= 1e-4 * scale
+    assert (a1 - a0).abs().max().item() > 1e-2 * scale      # the step really moved the output

@@ -67,7 +67,7 @@ def test_state_dict_contract(tag, model_name, backbone):
     assert m.ignore_prune_layer == list(g["ignore_prune_layer"])
 
 
-@pytest.mark.parametrize("tag,model_name,backbone", MODELS[:2])
+@pytest.mark.parametrize("tag,model_name,backbone", MODELS)
 def test_oracle_model_matches_reference(tag, model_name, backbone):
     g = _load(f"model_{tag}.npz")
     N, H, W, align = [int(v) for v in g["meta"]]
@@ -95,11 +95,13 @@ def test_oracle_model_matches_reference(tag, model_name, backbone):
     assert np.abs(sd["backbone.bn1.running_var"].numpy() - g["rv:backbone.bn1:32"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("gp", [50, 70])
-def test_oracle_masks_match_reference(gp):
+@pytest.mark.parametrize("tag,model_name,backbone,align,gp",
+                         [("v3r50", "deeplabv3", "resnet50", True, 50), ("v3r50", "deeplabv3", "resnet50", True, 70),
+                          ("v3r101", "deeplabv3", "resnet101", True, 50), ("simple_r50", "simple", "resnet50", False, 50)])
+def test_oracle_masks_match_reference(tag, model_name, backbone, align, gp):
     """Threshold + per-layer mask arithmetic of the oracle vs DCFPPruner in the reference."""
-    g = _load(f"prune_v3r50_gp{gp}.npz")
-    m, sd0 = product_state("deeplabv3", "resnet50", True)
+    g = _load(f"prune_{tag}_gp{gp}.npz")
+    m, sd0 = product_state(model_name, backbone, align)
     from oracle.make_scores import synthetic_scores
     eic = synthetic_scores(m)
     links = dict(zip(g["norm_conv_bn"].tolist(), g["norm_conv_conv"].tolist()))

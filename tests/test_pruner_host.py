@@ -16,23 +16,28 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 BB = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
 
 
-def build():
+def build(model="deeplabv3", backbone="resnet50", align=True):
     from dcfp_amd import networks
-    m = networks.deeplabv3.Seg_Model(backbone="resnet50", backbone_para=dict(BB), num_classes=19,
-                                     align_corner=True, deepsup=True)
+    m = getattr(networks, model).Seg_Model(backbone=backbone, backbone_para=dict(BB), num_classes=19,
+                                           align_corner=align, deepsup=True)
     m.load_state_dict(fill.closed_form_state(m.state_dict()))
     return m
 
 
-@pytest.mark.parametrize("gp", [50, 70])
-def test_prune_model_matches_reference(gp, tmp_path):
-    path = os.path.join(G, f"prune_v3r50_gp{gp}.npz")
+# (fixture tag, model, backbone, align_corner, global_percent): BASELINE config 5 is R101; `simple` is config 1
+PRUNE_CASES = [("v3r50", "deeplabv3", "resnet50", True, 50), ("v3r50", "deeplabv3", "resnet50", True, 70),
+               ("v3r101", "deeplabv3", "resnet101", True, 50), ("simple_r50", "simple", "resnet50", False, 50)]
+
+
+@pytest.mark.parametrize("tag,model,backbone,align,gp", PRUNE_CASES)
+def test_prune_model_matches_reference(tag, model, backbone, align, gp, tmp_path):
+    path = os.path.join(G, f"prune_{tag}_gp{gp}.npz")
     if not os.path.exists(path):
         pytest.skip("golden missing")
     g = np.load(path)
     from dcfp_amd import pruners
     from dcfp_amd.pruners.dcfp_pruner import DCFPPruner
-    m = build()
+    m = build(model, backbone, align)
     score = str(tmp_path / "score.pth")
     torch.save({"eic": synthetic_scores(m)}, score)
     pruner = DCFPPruner(global_percent=gp / 100.0, layer_keep=0.02, score_file=score)
@@ -64,11 +69,11 @@ def test_prune_model_matches_reference(gp, tmp_path):
     assert np.allclose(abss, g["pruned_abs"], rtol=1e-9, atol=1e-9)
 
     # slim model re-instantiated from channel_cfg (prune.py:100-110) and run by the oracle on CPU
-    slim = build()
+    slim = build(model, backbone, align)
     pruners.init_pruned_model(slim, cfg)
     assert [str(tuple(v.shape)) for v in slim.state_dict().values()] == g["slim_shapes"].tolist()
     slim.load_state_dict(sd)
-    ocfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
+    ocfg = omodel.Cfg(model=model, backbone=backbone, align_corner=align)
     outs, _, _ = omodel.seg_forward(omodel.clone_state(slim.state_dict(), requires_grad=False),
                                     fill.closed_form_input(2, 33, 33), ocfg, None, training=False)
     assert np.abs(outs[0].numpy() - g["slim_logits"]).max() < 1e-5
