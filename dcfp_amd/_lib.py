@@ -75,6 +75,8 @@ SIGNATURES = {
                                       _Z, _P]),
     "dcfp_upsample_ce_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "dcfp_ohem_zoom_gt_prob_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "dcfp_ohem_threshold_f32": (_I, [_P, _P, _L, _I, _F, _L, _P, _P]),
+    "dcfp_ohem_keep_mask_u8": (_I, [_P, _P, _L, _P, _P]),
     "dcfp_upsample_margin_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dcfp_maxfilter2d_s1_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dcfp_upsample_wce_workspace_bytes": (_Z, [_I, _I, _I]),

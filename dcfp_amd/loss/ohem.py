@@ -30,7 +30,14 @@ class OhemCrossEntropy2d(nn.Module):
 
     @torch.no_grad()
     def find_threshold(self, logits, target, lse, size, align_corner):
-        """ohem.py:20-48 on the device; returns a python float like the reference."""
+        """ohem.py:20-48; returns a python float like the reference (one host sync: not used by the
+        training path, which keeps the threshold on the device - threshold_device)."""
+        return float(self.threshold_device(logits, target, lse, size, align_corner).item())
+
+    @torch.no_grad()
+    def threshold_device(self, logits, target, lse, size, align_corner):
+        """ohem.py:20-48 entirely on the device: zoomed ground-truth probabilities -> exact radix select
+        of the k-th smallest valid one -> max(thresh, kth) as a one-float device tensor."""
         logits = logits.contiguous()
         N, Cc, h, w = logits.shape
         H, W = int(size[0]), int(size[1])
@@ -43,26 +50,22 @@ class OhemCrossEntropy2d(nn.Module):
             C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()), C.c_void_p(lse.data_ptr()),
             N, Cc, h, w, H, W, int(bool(align_corner)), H8, W8, C.c_void_p(pred8.data_ptr()),
             C.c_void_p(lab8.data_ptr()), stream), "ohem_zoom")
-        min_kept = self.min_kept // (f * f)
-        valid = lab8 != self.ignore_label
-        num_valid = int(valid.sum().item())
-        if min_kept >= num_valid:
-            return 1.0
-        threshold = self.thresh
-        if num_valid > 0 and min_kept > 0:
-            pred = pred8[valid]
-            k_th = min(pred.numel(), min_kept) - 1
-            kth_val = float(torch.kthvalue(pred, k_th + 1).values.item())
-            if kth_val > self.thresh:
-                threshold = kth_val
-        return threshold
+        thr = torch.empty(1, dtype=torch.float32, device=logits.device)
+        check(_lib.lib().dcfp_ohem_threshold_f32(
+            C.c_void_p(pred8.data_ptr()), C.c_void_p(lab8.data_ptr()), pred8.numel(), int(self.ignore_label),
+            float(self.thresh), int(self.min_kept // (f * f)), C.c_void_p(thr.data_ptr()), stream),
+            "ohem_threshold")
+        return thr
 
     def forward_lowres(self, logits, target, size, align_corner):
         target = target.contiguous()
         out2, lse, gtp = ops.upsample_ce_forward(logits.detach(), target, size, align_corner,
                                                  self.ignore_label, want_gt_prob=True)
-        threshold = self.find_threshold(logits.detach(), target, lse, size, align_corner)
-        keep = gtp <= threshold   # ohem.py:69: kept_flag = pred <= threshold
+        thr = self.threshold_device(logits.detach(), target, lse, size, align_corner)
+        keep = torch.empty(gtp.shape, dtype=torch.uint8, device=gtp.device)
+        check(_lib.lib().dcfp_ohem_keep_mask_u8(   # ohem.py:69: kept_flag = pred <= threshold
+            C.c_void_p(gtp.data_ptr()), C.c_void_p(thr.data_ptr()), gtp.numel(), C.c_void_p(keep.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ohem_keep_mask")
         return ops.upsample_cross_entropy(logits, target, size, align_corner, self.ignore_label,
                                           pixel_keep=keep)
 

@@ -229,6 +229,21 @@ int dcfp_ohem_zoom_gt_prob_f32(const float* logits, const int64_t* labels, const
                                int H8, int W8, float* pred8, int32_t* lab8,
                                dcfp_stream_t stream);
 
+/* OHEM threshold (loss/ohem.py:34-48, np.partition on the host in the reference) on the device:
+ *   num_valid = #(lab8 != ignore_label) over the n zoomed positions;
+ *   min_kept >= num_valid -> 1.0;  min_kept <= 0 -> thresh;  otherwise
+ *   kth = the (min(num_valid, min_kept)-1)-th smallest pred8 among valid positions (exact radix
+ *   select), *threshold = kth > thresh ? kth : thresh.  min_kept is the reference's
+ *   `self.min_kept // (factor*factor)`.  threshold: ONE float in device memory, consumed by
+ *   dcfp_ohem_keep_mask_u8 without a host round trip. */
+int dcfp_ohem_threshold_f32(const float* pred8, const int32_t* lab8, int64_t n, int ignore_label,
+                            float thresh, int64_t min_kept, float* threshold /* device scalar */,
+                            dcfp_stream_t stream);
+/* keep[i] = gt_prob[i] <= *threshold (loss/ohem.py:69 kept_flag) over the n full-resolution pixels:
+ * the pixel_keep mask of dcfp_upsample_ce_{fwd,bwd}_f32.  gt_prob 16-byte, keep 4-byte aligned. */
+int dcfp_ohem_keep_mask_u8(const float* gt_prob, const float* threshold /* device scalar */, int64_t n,
+                           uint8_t* keep, dcfp_stream_t stream);
+
 /* GSRL fine-tune loss (loss/criterion.py:77-101), fused the same way as the CE above:
  *   margin[pix]  = p1 - p2, the two largest softmax probabilities of the interpolated logits
  *                  (replaces softmax + sort over the full-resolution tensor, :89-91);

@@ -227,6 +227,104 @@ def test_ohem_threshold_and_loss_vs_oracle(cuda, case):
         assert rel_err(zg.grad, zr.grad) < 1e-3
 
 
+def _ohem_select(pred, lab, thresh, min_kept, cuda, ignore=255):
+    from dcfp_amd import _lib
+    import ctypes as C
+    p = torch.from_numpy(pred.astype("float32")).to(cuda).contiguous()
+    l = torch.from_numpy(lab.astype("int32")).to(cuda).contiguous()
+    out = torch.full((1,), -7.0, device=cuda)
+    _lib.check(_lib.lib().dcfp_ohem_threshold_f32(C.c_void_p(p.data_ptr()), C.c_void_p(l.data_ptr()), p.numel(), ignore,
+                                                  float(thresh), int(min_kept), C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ohem_threshold")
+    return out.cpu().numpy()[0]
+
+
+@pytest.mark.parametrize("case", ["kth_le", "kth_gt", "few_valid"])
+def test_ohem_select_kernel_bit_equal_to_reference_golden(cuda, case):
+    """dcfp_ohem_threshold_f32 (device radix select) on the reference's own zoomed arrays: the threshold
+    must be the golden value bit for bit (loss/ohem.py:20-48; np.partition there)."""
+    import os
+    import numpy as np
+    import scipy.ndimage as nd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ohem_threshold.npz"))
+    prob = torch.softmax(torch.from_numpy(g[f"z:{case}"]), 1).numpy()
+    lab = g[f"lab:{case}"]
+    pz = nd.zoom(prob, (1.0, 1.0, 1 / 8, 1 / 8), order=1)          # ohem.py:23-24
+    lz = nd.zoom(lab, (1.0, 1 / 8, 1 / 8), order=0).astype(np.int32)
+    n, c, h, w = pz.shape
+    flat = np.rollaxis(pz, 1).reshape(c, -1)
+    lflat = lz.ravel()
+    gt = np.where(lflat != 255, flat[np.minimum(lflat, c - 1), np.arange(lflat.size)], 1.0).astype(np.float32)
+    th = _ohem_select(gt, lflat, 0.7, int(g[f"min_kept:{case}"]) // 64, cuda)
+    assert np.float32(th) == np.float32(g[f"th:{case}"]), (th, g[f"th:{case}"])
+
+
+def test_ohem_select_kernel_vs_partition(cuda):
+    """Exact k-th smallest among valid positions vs np.partition: ties, negatives, ragged n, all-ignored,
+    min_kept >= valid, min_kept == 0."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 1024, 4097, 131072, 300001):
+        pred = rng.random(n, dtype=np.float32)
+        pred[rng.random(n) < 0.2] = np.float32(0.25)            # many exact ties
+        if n > 100:
+            pred[:50] = -pred[:50]                              # order-preserving key handles negatives
+        lab = rng.integers(0, 19, n).astype(np.int32)
+        lab[rng.random(n) < 0.3] = 255
+        valid = pred[lab != 255]
+        for mk in (0, 1, 2, max(1, valid.size // 3), valid.size - 1, valid.size, valid.size + 5):
+            if mk < 0:
+                continue
+            got = _ohem_select(pred, lab, 0.1, mk, cuda)
+            if mk >= valid.size:
+                want = np.float32(1.0)
+            elif mk == 0:
+                want = np.float32(0.1)
+            else:
+                kth = np.partition(valid, mk - 1)[mk - 1]
+                want = kth if kth > np.float32(0.1) else np.float32(0.1)
+            assert np.float32(got) == np.float32(want), (n, mk, got, want)
+    assert _ohem_select(np.zeros(10, np.float32), np.full(10, 255, np.int32), 0.7, 0, cuda) == np.float32(1.0)
+
+
+def test_ohem_fullsize_vs_oracle(cuda):
+    """BASELINE config-3 geometry: 4 x 19 x 128 x 256 logits -> 1024 x 2048, min_kept 100000, against
+    oracle.ohem.new_target on the materialised full-resolution softmax (loss/ohem.py:51-78).  The training
+    path makes no host synchronisation and calls no ATen select (threshold stays on the device)."""
+    import numpy as np
+    from oracle import ohem as oohem
+    from dcfp_amd import ops
+    from dcfp_amd.loss.ohem import OhemCrossEntropy2d
+    N, Cc, h, w, H, W = 4, 19, 128, 256, 1024, 2048
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(N, Cc, h, w, generator=g) * 2.0
+    lab = torch.randint(0, Cc, (N, H, W), generator=g)
+    lab[torch.rand(N, H, W, generator=g) < 0.05] = 255
+    # make the label class likely on most pixels so that probabilities straddle 0.7
+    zl = F.interpolate(F.one_hot(lab.clamp(max=Cc - 1), Cc).permute(0, 3, 1, 2).float(), size=(h, w), mode="bilinear",
+                       align_corners=True)
+    z = z + 4.0 * zl * torch.rand(N, 1, h, w, generator=g)
+    for mk, thresh in ((100000, 0.7), (100000 * 40, 0.3)):        # threshold = thresh, and threshold = k-th value
+        up = F.interpolate(z, size=(H, W), mode="bilinear", align_corners=True)
+        prob = torch.softmax(up, 1).numpy()
+        new_t, th = oohem.new_target(prob, lab.numpy(), 255, thresh, mk)
+        del prob
+        crit = OhemCrossEntropy2d(ignore_label=255, thresh=thresh, min_kept=mk)
+        zg = z.to(cuda).requires_grad_(True); lg = lab.to(cuda)
+        out2, lse, gtp = ops.upsample_ce_forward(zg.detach(), lg, (H, W), True, 255, want_gt_prob=True)
+        thr = crit.threshold_device(zg.detach(), lg, lse, (H, W), True)
+        assert thr.is_cuda and thr.numel() == 1
+        assert abs(thr.item() - float(th)) <= 2e-6 * max(1.0, abs(float(th))), (thr.item(), th)
+        loss = crit.forward_lowres(zg, lg, (H, W), True)
+        loss.backward()
+        ref = F.cross_entropy(up.double(), torch.from_numpy(new_t).long(), ignore_index=255)
+        kept_ref = int((new_t != 255).sum())
+        kept = int(((gtp <= thr) & (lg != 255)).sum().item())
+        assert abs(kept - kept_ref) <= max(8, 2e-5 * kept_ref), (kept, kept_ref)     # pixels within an ulp of the threshold
+        assert abs(loss.item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+        assert torch.isfinite(zg.grad).all()
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_gsrl_loss_vs_reference_golden(cuda, tag):
     """CriterionGsrlDSN through the fused HIP kernels vs the reference's output (golden)."""
