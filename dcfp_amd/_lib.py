@@ -33,33 +33,40 @@ class SgdEntry(C.Structure):
                 ("weight_decay", C.c_float), ("pad_", C.c_int32)]
 
 
+class BnRunning(C.Structure):
+    """DcfpBnRunning: nn.BatchNorm2d's training-mode bookkeeping folded into the statistics kernels."""
+    _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+                ("momentum", C.c_float), ("pad_", C.c_int32)]
+
+
 SGD_CHUNK = 16384
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 E_BADDESC, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3   # DCFP_E_* of include/dcfp_hip.h
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
+_R = C.POINTER(BnRunning)
 
 # name -> (restype, argtypes); mirrors include/dcfp_hip.h one to one
 SIGNATURES = {
     "dcfp_abi_version": (_I, []),
     "dcfp_conv2d_workspace_bytes": (_Z, [_D, _I]),
     "dcfp_conv2d_kernel_name": (_I, [_D, _I, C.c_char_p, _I]),
-    "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P, _Z, _P]),
-    "dcfp_conv2d_fwd_fused_f32_nchw": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
-    "dcfp_conv2d_dgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _I, _P, _Z, _P]),
+    "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P, _Z, _I, _P]),
+    "dcfp_conv2d_fwd_fused_f32_nchw": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P]),
+    "dcfp_conv2d_dgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _I, _P, _Z, _I, _P]),
     "dcfp_conv2d_wgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _P, _P, _Z, _P]),
     "dcfp_bn_workspace_bytes": (_Z, [_I, _I, _I]),
-    "dcfp_bn_stats_f32": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "dcfp_bn_stats_f32": (_I, [_P, _L, _I, _I, _I, _P, _P, _R, _P, _Z, _P]),
     "dcfp_bn_apply_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P, _L, _I, _I, _I, _P]),
-    "dcfp_bn_bwd_reduce_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P,
+    "dcfp_bn_bwd_reduce_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P,
                                     _P, _Z, _P]),
     "dcfp_bn_update_running_f32": (_I, [_P, _P, _I, _F, _F, _P, _P, _P, _P]),
-    "dcfp_syncbn_combine_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "dcfp_syncbn_combine_f32": (_I, [_P, _I, _I, _P, _P, _P, _R, _P]),
     "dcfp_bn_apply_relu_mask_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "dcfp_conv2d_fwd_stat_slots": (_L, [_D, _P, _L]),
-    "dcfp_conv2d_fwd_stats_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _P, _Z, _P]),
-    "dcfp_bn_stats_from_partials_f32": (_I, [_P, _L, _I, _I, _P, _P, _P]),
+    "dcfp_conv2d_fwd_stats_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _P, _Z, _I, _P]),
+    "dcfp_bn_stats_from_partials_f32": (_I, [_P, _L, _I, _I, _P, _P, _R, _P]),
     "dcfp_bn_bwd_apply_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _P, _P, _F, _P, _I, _P, _P,
                                    _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -17,6 +17,16 @@ __device__ __forceinline__ float bn_val(float v, float mu, float istd, float g, 
     return fmaf((v - mu) * istd, g, b);
 }
 
+// nn.BatchNorm2d's training-mode bookkeeping for channel c, done by the thread that finalises it
+__device__ __forceinline__ void running_update(const DcfpBnRunning& r, int c, float mean, float var, float n) {
+    if (r.running_mean) {
+        const float unb = n / fmaxf(n - 1.0f, 1.0f);
+        r.running_mean[c] = r.running_mean[c] * (1.0f - r.momentum) + r.momentum * mean;
+        r.running_var[c] = r.running_var[c] * (1.0f - r.momentum) + r.momentum * (var * unb);
+    }
+    if (c == 0 && r.num_batches_tracked) r.num_batches_tracked[0] += 1;
+}
+
 struct BnPlan {
     int chunks;       // blocks per channel
     int chunk_elems;  // elements (of the N*HW per-channel population) per block, multiple of 4
@@ -80,7 +90,7 @@ bn_stats_partial_kernel(const float* __restrict__ x, long long nstride, int HW, 
 
 __global__ void bn_stats_final_kernel(const float* __restrict__ x, int HW, long long E, int C,
                                       int chunks, const float* __restrict__ part,
-                                      float* __restrict__ mean, float* __restrict__ var) {
+                                      float* __restrict__ mean, float* __restrict__ var, DcfpBnRunning run) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double S1 = 0.0, S2 = 0.0;
@@ -94,6 +104,7 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, int HW, long 
     if (v < 0.0) v = 0.0;
     mean[c] = (float)(K + m1);
     var[c] = (float)v;
+    running_update(run, c, (float)(K + m1), (float)v, (float)E);
 }
 
 // ReLU bit mask of a residual BatchNorm (one bit per element instead of re-reading the 4-byte output
@@ -230,7 +241,8 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
 // o3 (nullable): dgamma = sum(dy*(x-mean)) * rsqrt(var + eps), saving the caller three launches
 __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict__ part,
                                      float* __restrict__ o1, float* __restrict__ o2,
-                                     const float* __restrict__ var, float eps, float* __restrict__ o3) {
+                                     const float* __restrict__ var, float eps, float* __restrict__ o3,
+                                     float* __restrict__ o4) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double S1 = 0.0, S2 = 0.0;
@@ -241,31 +253,35 @@ __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict_
     o1[c] = (float)S1;
     o2[c] = (float)S2;
     if (o3) o3[c] = (float)S2 * rsqrtf(var[c] + eps);
+    if (o4) o4[c] = (float)S1;
 }
 
 // SyncBatchNorm forward combine: allv[r] = (mean_r[C], var_r[C], count_r) gathered from every rank ->
 // pooled mean / biased variance over all ranks' pixels (parallel-variance combination), one launch
 __global__ void syncbn_combine_kernel(const float* __restrict__ allv, int world, int C,
                                       float* __restrict__ gmean, float* __restrict__ gvar,
-                                      float* __restrict__ total) {
+                                      float* __restrict__ total, DcfpBnRunning run) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int S = 2 * C + 1;
+    // fp64, rank order, every product and sum rounded on its own (no FMA contraction): the host path
+    // (ops.syncbn_combine_reference) evaluates the same expression with torch and must agree bit for bit
     double tot = 0.0, m = 0.0, v = 0.0;
     for (int r = 0; r < world; ++r) {
         const double n = (double)allv[(long long)r * S + 2 * C];
-        tot += n;
-        m += (double)allv[(long long)r * S + c] * n;
+        tot = __dadd_rn(tot, n);
+        m = __dadd_rn(m, __dmul_rn((double)allv[(long long)r * S + c], n));
     }
     m /= tot;
     for (int r = 0; r < world; ++r) {
         const double n = (double)allv[(long long)r * S + 2 * C];
-        const double d = (double)allv[(long long)r * S + c] - m;
-        v += ((double)allv[(long long)r * S + C + c] + d * d) * n;
+        const double d = __dadd_rn((double)allv[(long long)r * S + c], -m);
+        v = __dadd_rn(v, __dmul_rn(__dadd_rn((double)allv[(long long)r * S + C + c], __dmul_rn(d, d)), n));
     }
     gmean[c] = (float)m;
     gvar[c] = (float)(v / tot);
     if (c == 0) total[0] = (float)tot;
+    running_update(run, c, (float)m, (float)(v / tot), (float)tot);
 }
 
 // Batch statistics from the conv epilogue's partials: part[s][c] = (mean_s, M2_s) of `cnt` values
@@ -273,7 +289,7 @@ __global__ void syncbn_combine_kernel(const float* __restrict__ allv, int world,
 //   mean = avg(mean_s),  var = (sum M2_s + cnt * sum (mean_s - mean)^2) / (S * cnt)   (biased)
 __global__ void __launch_bounds__(kThreads)
 bn_stats_from_partials_kernel(const float* __restrict__ part, long long S, int cnt, int C,
-                              float* __restrict__ mean, float* __restrict__ var) {
+                              float* __restrict__ mean, float* __restrict__ var, DcfpBnRunning run) {
     __shared__ double red[kThreads];
     const int c = blockIdx.x;
     double a = 0.0;
@@ -298,8 +314,10 @@ bn_stats_from_partials_kernel(const float* __restrict__ part, long long S, int c
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        const float v = (float)(red[0] / ((double)S * (double)cnt));
         mean[c] = (float)mu;
-        var[c] = (float)(red[0] / ((double)S * (double)cnt));
+        var[c] = v;
+        running_update(run, c, (float)mu, v, (float)((double)S * (double)cnt));
     }
 }
 
@@ -394,10 +412,19 @@ extern "C" size_t dcfp_bn_workspace_bytes(int N, int C, int HW) {
     return (size_t)C * p.chunks * 2 * sizeof(float);
 }
 
+static int run_arg(const DcfpBnRunning* run, DcfpBnRunning* out) {
+    DcfpBnRunning none = {nullptr, nullptr, nullptr, 0.f, 0};
+    *out = run ? *run : none;
+    if (out->running_mean && !out->running_var) return DCFP_E_BADDESC;
+    return DCFP_OK;
+}
+
 extern "C" int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C, int HW,
-                                 float* mean, float* var, void* workspace,
+                                 float* mean, float* var, const DcfpBnRunning* run, void* workspace,
                                  size_t workspace_bytes, dcfp_stream_t stream) {
     if (!x || !mean || !var || N <= 0 || C <= 0 || HW <= 0) return DCFP_E_BADDESC;
+    DcfpBnRunning rn;
+    if (run_arg(run, &rn)) return DCFP_E_BADDESC;
     if (x_nstride == 0) x_nstride = (int64_t)C * HW;
     const BnPlan p = bn_plan(N, C, HW);
     if (!workspace || workspace_bytes < (size_t)C * p.chunks * 2 * sizeof(float))
@@ -413,7 +440,7 @@ extern "C" int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C
         hipLaunchKernelGGL(bn_stats_partial_kernel<false>, grid, dim3(kThreads), 0, dcfp_s(stream),
                            x, (long long)x_nstride, HW, E, p.chunk_elems, p.chunks, part);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream),
-                       x, HW, E, C, p.chunks, part, mean, var);
+                       x, HW, E, C, p.chunks, part, mean, var, rn);
     DCFP_RETURN_LAUNCH();
 }
 
@@ -463,7 +490,7 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
                                       const float* y, int64_t y_nstride, const float* mean,
                                       const float* var, const float* gamma, const float* beta,
                                       float eps, int relu, int N, int C, int HW, float* sum_dy,
-                                      float* sum_dy_xmu, float* dgamma, void* workspace,
+                                      float* sum_dy_xmu, float* dgamma, float* dbeta, void* workspace,
                                       size_t workspace_bytes, dcfp_stream_t stream) {
     if (dgamma && !var) return DCFP_E_BADDESC;
     if (!dy || !x || !mean || !sum_dy || !sum_dy_xmu || N <= 0 || C <= 0 || HW <= 0)
@@ -490,7 +517,7 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
     else     { if (relu == 2) LAUNCH_RED(false, 2); else if (relu == 1) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
     hipLaunchKernelGGL(bn_pair_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C,
-                       p.chunks, part, sum_dy, sum_dy_xmu, var, eps, dgamma);
+                       p.chunks, part, sum_dy, sum_dy_xmu, var, eps, dgamma, dbeta);
     DCFP_RETURN_LAUNCH();
 }
 
@@ -538,17 +565,22 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
 }
 
 extern "C" int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean, float* var,
-                                       float* total_count, dcfp_stream_t stream) {
+                                       float* total_count, const DcfpBnRunning* run, dcfp_stream_t stream) {
     if (!gathered || !mean || !var || !total_count || world <= 0 || C <= 0) return DCFP_E_BADDESC;
+    DcfpBnRunning rn;
+    if (run_arg(run, &rn)) return DCFP_E_BADDESC;
     hipLaunchKernelGGL(syncbn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream),
-                       gathered, world, C, mean, var, total_count);
+                       gathered, world, C, mean, var, total_count, rn);
     DCFP_RETURN_LAUNCH();
 }
 
 extern "C" int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t slots, int slot_count, int C,
-                                               float* mean, float* var, dcfp_stream_t stream) {
+                                               float* mean, float* var, const DcfpBnRunning* run,
+                                               dcfp_stream_t stream) {
     if (!partials || !mean || !var || slots <= 0 || slot_count <= 0 || C <= 0) return DCFP_E_BADDESC;
+    DcfpBnRunning rn;
+    if (run_arg(run, &rn)) return DCFP_E_BADDESC;
     hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((unsigned)C), dim3(kThreads), 0, dcfp_s(stream),
-                       partials, (long long)slots, slot_count, C, mean, var);
+                       partials, (long long)slots, slot_count, C, mean, var, rn);
     DCFP_RETURN_LAUNCH();
 }

@@ -37,7 +37,7 @@ int check_desc(const DcfpConvDesc* d) {
 
 }  // namespace
 
-extern "C" int dcfp_abi_version(void) { return 1; }
+extern "C" int dcfp_abi_version(void) { return 2; }
 
 // implemented in conv_wgrad.hip / conv_igemm2.hip
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len);
@@ -48,7 +48,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale = nullptr, const float* shift = nullptr,
-                    const float* residual = nullptr, int relu = 0, float* stat_part = nullptr);
+                    const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0);
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 
@@ -60,7 +60,7 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
                     void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale = nullptr, const float* shift = nullptr,
-                    const float* residual = nullptr, int relu = 0);
+                    const float* residual = nullptr, int relu = 0, int wp_valid = 0);
 int dcfp_igemm2_cfg_id(int M, long long px, int sd);
 static bool math_bf16x3() {
     static const bool v = [] { const char* e = getenv("DCFP_CONV_MATH"); return e && !strcmp(e, "bf16x3"); }();
@@ -109,7 +109,7 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
 
 extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                                         const float* bias, float* y, int64_t y_nstride,
-                                        void* workspace, size_t workspace_bytes,
+                                        void* workspace, size_t workspace_bytes, int wp_valid,
                                         dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -119,11 +119,12 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                                y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                                d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, -d->pad, d->dil, 0,
-                               workspace, workspace_bytes, dcfp_s(stream));
+                               workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0, wp_valid);
     return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                            y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                            d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
-                           d->dil, 0, workspace, workspace_bytes, dcfp_s(stream));
+                           d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0,
+                           nullptr, wp_valid);
 }
 
 // Forward conv that also emits BatchNorm batch-statistics partials of its output (see
@@ -137,7 +138,7 @@ extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float
 
 extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                                               float* y, int64_t y_nstride, float* stat_partials,
-                                              void* workspace, size_t workspace_bytes,
+                                              void* workspace, size_t workspace_bytes, int wp_valid,
                                               dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -148,13 +149,13 @@ extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float
                            y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                            d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
                            d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr,
-                           nullptr, 0, stat_partials);
+                           nullptr, 0, stat_partials, wp_valid);
 }
 
 extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy,
                                           int64_t dy_nstride, const float* w, float* dx,
                                           int accumulate, void* workspace, size_t workspace_bytes,
-                                          dcfp_stream_t stream) {
+                                          int wp_valid, dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !w || !dx) return DCFP_E_BADDESC;
@@ -163,18 +164,20 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         return dcfp_igemm3_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
                                T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
                                d->Cout, T, d->Hout, d->Wout, d->H, d->W, d->pad, -d->dil,
-                               accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream));
+                               accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr,
+                               nullptr, 0, wp_valid);
     return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
                            T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
                            d->Cout, T, d->Hout, d->Wout, d->H, d->W, 1, d->stride, d->pad, -d->dil,
-                           accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream));
+                           accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0,
+                           nullptr, wp_valid);
 }
 
 // Inference: conv + folded eval-mode BatchNorm (+residual) (+ReLU) in the conv epilogue.
 extern "C" int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                                               const float* scale, const float* shift,
                                               const float* residual, int relu, float* y,
-                                              void* workspace, size_t workspace_bytes,
+                                              void* workspace, size_t workspace_bytes, int wp_valid,
                                               dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -184,9 +187,9 @@ extern "C" int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
                                (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,
                                d->Hout, d->Wout, -d->pad, d->dil, 0, workspace, workspace_bytes,
-                               dcfp_s(stream), scale, shift, residual, relu ? 1 : 0);
+                               dcfp_s(stream), scale, shift, residual, relu ? 1 : 0, wp_valid);
     return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
                            (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,
                            d->Hout, d->Wout, d->stride, 1, -d->pad, d->dil, 0, workspace, workspace_bytes,
-                           dcfp_s(stream), scale, shift, residual, relu ? 1 : 0);
+                           dcfp_s(stream), scale, shift, residual, relu ? 1 : 0, nullptr, wp_valid);
 }

@@ -857,7 +857,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale, const float* shift, const float* residual, int relu,
-                    float* stat_part) {
+                    float* stat_part, int wp_valid) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
@@ -882,7 +882,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     if (!workspace || workspace_bytes < need || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
     float* wp = static_cast<float*>(workspace);
     p.wp = wp;
-    {
+    if (!wp_valid) {   // (the caller's buffer already holds Wp of these weights for this pass and shape otherwise)
         const long long total = (long long)T * p.CkP * p.Mpad;
         long long b = (total + 255) / 256;
         if (b > 2048) b = 2048;

@@ -511,7 +511,7 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
                     const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
                     int Hi, int Wi, int Ho, int Wo, int off0, int offstep, int accumulate,
                     void* workspace, size_t workspace_bytes, hipStream_t stream, const float* scale,
-                    const float* shift, const float* residual, int relu) {
+                    const float* shift, const float* residual, int relu, int wp_valid) {
     Igemm3Params p;
     if (bias) return DCFP_E_UNSUPPORTED;   // callers route bias convs to the fp32 kernel
     p.in = in; p.out = out;
@@ -530,7 +530,7 @@ int dcfp_igemm3_run(const float* in, long long in_nstride, const float* w, int s
     if ((long long)Ck * Hi * Wi * 4 > 0x7fffffffLL || need > 0x7fffffffULL) return DCFP_E_UNSUPPORTED;
     __bf16* wp3 = static_cast<__bf16*>(workspace);
     p.wp3 = wp3;
-    {
+    if (!wp_valid) {
         const long long total = (long long)T * p.CkP * p.Mpad;
         long long b = (total + 255) / 256;
         if (b > 4096) b = 4096;

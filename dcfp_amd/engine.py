@@ -11,6 +11,39 @@ import torch.distributed as dist
 from .utils.pyt_utils import all_reduce_tensor
 
 
+class DataParallel(torch.nn.Module):
+    """What torch's DistributedDataParallel does for the reference (engine.py:66-68), on the arenas of
+    dcfp_amd/arena.py: at construction rank 0's parameters and buffers are broadcast (ONE collective for
+    the parameter arena, one per buffer dtype); in backward the kernels write gradients straight into the
+    gradient arena and arena.GradReducer averages it over the ranks in a few large all-reduces issued as
+    soon as their range is complete; `loss.backward()` returns with averaged gradients in place.
+    `.module` is the wrapped model, as with DDP."""
+
+    def __init__(self, module, group=None, n_chunks=3):
+        super().__init__()
+        from .arena import ParamArena, GradReducer
+        self.module = module
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.arena = ParamArena.of(params)
+        self.group = group
+        with torch.no_grad():
+            dist.broadcast(self.arena.flat_param, 0, group=group)
+            by_dtype = {}
+            for b in module.buffers():
+                by_dtype.setdefault(b.dtype, []).append(b)
+            for dt, bufs in by_dtype.items():
+                flat = torch.cat([b.reshape(-1) for b in bufs])
+                dist.broadcast(flat, 0, group=group)
+                off = 0
+                for b in bufs:
+                    b.copy_(flat[off:off + b.numel()].view(b.shape))
+                    off += b.numel()
+        self.reducer = GradReducer(self.arena, group, n_chunks)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
 class Engine(object):
     def __init__(self, custom_parser=None, backend=None):
         self.distributed = False
@@ -48,17 +81,22 @@ class Engine(object):
         if "local_rank" not in have:
             p.add_argument("--local_rank", default=0, type=int, help="process rank on node")
 
-    def data_parallel(self, model, bucket_cap_mb=128):
-        """SyncBatchNorm conversion + DDP (engine.py:63-71).  The BN layers stay parameter
-        holders; their SyncBN semantics are executed by dcfp_amd.ops.BatchNormActFn.  Buckets
-        are large (default 128 MB): xGMI rings are per-link bound and the step is compute-bound,
-        so few big all-reduces overlapped with backward beat many small ones."""
+    def data_parallel(self, model, n_chunks=3, torch_ddp=False, bucket_cap_mb=128):
+        """SyncBatchNorm conversion + gradient-averaging wrapper (engine.py:63-71).  The BN layers stay
+        parameter holders; their SyncBN semantics are executed by dcfp_amd.ops.  The wrapper is
+        dcfp_amd.engine.DataParallel: parameters / gradients in flat arenas, the gradient exchange as
+        `n_chunks` contiguous all-reduces over RCCL overlapped with backward (xGMI rings are per-link bound
+        and the step is compute-bound, so few ~87 MB messages beat many small buckets).
+        torch_ddp=True wraps in torch's DistributedDataParallel instead (set DCFP_ARENA_DIRECT=0 with it:
+        its hooks need the gradients to pass through autograd)."""
         if self.distributed:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-            ids = [self.local_rank] if torch.cuda.is_available() else None
-            model = torch.nn.parallel.DistributedDataParallel(
-                model, device_ids=ids, output_device=self.local_rank if ids else None,
-                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+            if torch_ddp:
+                ids = [self.local_rank] if torch.cuda.is_available() else None
+                return torch.nn.parallel.DistributedDataParallel(
+                    model, device_ids=ids, output_device=self.local_rank if ids else None,
+                    bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+            model = DataParallel(model, n_chunks=n_chunks)
         return model
 
     def all_reduce_tensor(self, tensor, norm=True):

@@ -24,28 +24,33 @@ FUSE_BLOCKS = os.environ.get("DCFP_NO_BLOCK_FUSION") is None
 
 
 def _bn_args(m):
-    """(running_mean, running_var, training, momentum, eps, sync) of a BN module, with the
-    module-side bookkeeping nn.BatchNorm2d.forward does (num_batches_tracked)."""
+    """(running_mean, running_var, training, momentum, eps, sync, num_batches_tracked) of a BN module.
+    The module-side bookkeeping of nn.BatchNorm2d.forward (num_batches_tracked += 1) is done by the HIP
+    kernel that finalises the batch statistics, which is handed the buffer; only the cumulative-average
+    mode (momentum=None: the factor depends on the counter's value) does it here, with a host read."""
     training = m.training or (m.running_mean is None)
     sync = False
     if isinstance(m, nn.SyncBatchNorm) and training:
         sync = m.process_group if m.process_group is not None else True
     momentum = m.momentum
+    nbt = None
     if training:
         m._dcfp_fold = None     # running statistics are about to change through raw pointers
     if training and m.track_running_stats and m.num_batches_tracked is not None:
-        m.num_batches_tracked.add_(1)
         if momentum is None:
+            m.num_batches_tracked.add_(1)
             momentum = 1.0 / float(m.num_batches_tracked)
+        else:
+            nbt = m.num_batches_tracked
     if not m.affine:
         raise RuntimeError("dcfp_amd: BatchNorm without affine parameters is not on the DCFP path")
-    return (m.running_mean, m.running_var, training, momentum, m.eps, sync)
+    return (m.running_mean, m.running_var, training, momentum, m.eps, sync, nbt)
 
 
 def bn_act(m, x, relu=False, residual=None):
     """BatchNorm2d / SyncBatchNorm (+ReLU) (+residual add before the ReLU)."""
-    rm, rv, training, momentum, eps, sync = _bn_args(m)
-    return ops.batch_norm_act(x, m.weight, m.bias, rm, rv, residual, relu, training, momentum, eps, sync)
+    rm, rv, training, momentum, eps, sync, nbt = _bn_args(m)
+    return ops.batch_norm_act(x, m.weight, m.bias, rm, rv, residual, relu, training, momentum, eps, sync, nbt)
 
 
 def _fold(bn):

@@ -89,7 +89,11 @@ class ResNet(nn.Module):
             for blk in getattr(self, "layer" + str(i)):
                 x = blk(x)
             if i in self.out_index:
-                outs.append(x)
+                if i < 4:    # this stage's output has two consumers: the head that taps it and the next stage
+                    tap, x = ops.fork(x)
+                    outs.append(tap)
+                else:
+                    outs.append(x)
         return tuple(outs)
 
 

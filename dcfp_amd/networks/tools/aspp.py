@@ -45,11 +45,32 @@ class ASPP(nn.Module):
             self.relu = nn.ReLU(inplace=True)
         self.dropout = nn.Dropout2d(0.1)
 
+    def _fused_ok(self):
+        br = [self.aspp1, self.aspp2, self.aspp3, self.aspp4]
+        pool = list(self.global_avg_pool.children())
+        return (all(m.atrous_conv.bias is None and m.atrous_conv.stride == (1, 1) and m.atrous_conv.groups == 1
+                    for m in br) and len(pool) == 4 and isinstance(pool[1], nn.Conv2d) and pool[1].bias is None
+                and pool[1].kernel_size == (1, 1))
+
     def forward(self, x):
-        x1, x2, x3, x4 = self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)
-        x5 = _exec.run_sequential(self.global_avg_pool, x)
-        x5 = ops.broadcast_to_hw(x5, x4.shape[2], x4.shape[3])
-        x = torch.cat((x1, x2, x3, x4, x5), dim=1)
+        if _exec.FUSE_BLOCKS and torch.is_grad_enabled() and x.requires_grad and self._fused_ok():
+            # training: branches + concat as one autograd node writing channel slices (no torch.cat, input
+            # gradients accumulated by the dgrad epilogue)
+            br = [self.aspp1, self.aspp2, self.aspp3, self.aspp4]
+            pool = list(self.global_avg_pool.children())
+            tensors, bns = [], []
+            for m in br:
+                tensors += [m.atrous_conv.weight, m.bn.weight, m.bn.bias]
+                bns.append(_exec._bn_args(m.bn))
+            tensors += [pool[1].weight, pool[2].weight, pool[2].bias]
+            bns.append(_exec._bn_args(pool[2]))
+            cfg = {"convs": [(m.atrous_conv.padding[0], m.atrous_conv.dilation[0]) for m in br], "bn": bns}
+            x = ops.aspp_branches(x, cfg, tensors)
+        else:
+            x1, x2, x3, x4 = self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)
+            x5 = _exec.run_sequential(self.global_avg_pool, x)
+            x5 = ops.broadcast_to_hw(x5, x4.shape[2], x4.shape[3])
+            x = torch.cat((x1, x2, x3, x4, x5), dim=1)
         if self.outplanes is not None:
             x = _exec.conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return x

@@ -10,8 +10,8 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import _lib
-from ._lib import ConvDesc, check
+from . import _lib, arena
+from ._lib import ConvDesc, BnRunning, check
 
 _ws_cache = {}
 # Bumped whenever parameters are rewritten through raw pointers (FusedSGD.step, load_state_dict):
@@ -118,31 +118,85 @@ FUSE_BN_STATS = os.environ.get("DCFP_FUSED_BN_STATS", "1") not in ("0",)
 BN_RELU_BITMASK = os.environ.get("DCFP_BN_RELU_BITMASK", "1") not in ("0",)
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
+def _wp_buffer(w, which, d, nbytes):
+    """Persistent buffer for the permuted weight copy Wp of (weight tensor, pass, shape) and whether the
+    library may skip rebuilding it: weights change once per optimizer step, so forward and dgrad each
+    permute at most once per step instead of on every call (`wp_valid` of include/dcfp_hip.h).  Validity =
+    same storage, same torch version counter and same WEIGHT_EPOCH (raw-pointer writes by FusedSGD)."""
+    key = (which, d.N, d.H, d.W, d.stride, d.pad, d.dil)
+    tag = (w.data_ptr(), w._version, WEIGHT_EPOCH[0], torch.cuda.current_stream().cuda_stream)
+    cache = getattr(w, "_dcfp_wp", None)
+    if cache is None:
+        cache = {}
+        try:
+            w._dcfp_wp = cache
+        except Exception:        # not an attribute-bearing tensor: no caching
+            return _workspace("conv", nbytes, w.device), 0
+    ent = cache.get(key)
+    if ent is not None and ent[1].numel() >= nbytes:
+        if ent[0] == tag:
+            return ent[1], 1
+        cache[key] = (tag, ent[1])
+        return ent[1], 0
+    if len(cache) > 8:           # shapes keep changing (multi-scale evaluation): do not hoard buffers
+        cache.clear()
+    buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=w.device)
+    cache[key] = (tag, buf)
+    return buf, 0
+
+
+def _bn_run(running_mean, running_var, momentum, nbt):
+    """DcfpBnRunning for the statistics kernels (None: nothing to update)."""
+    upd = running_mean is not None and momentum is not None
+    if not upd and nbt is None:
+        return None
+    r = BnRunning()
+    r.running_mean = running_mean.data_ptr() if upd else None
+    r.running_var = running_var.data_ptr() if upd else None
+    r.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
+    r.momentum = float(momentum) if upd else 0.0
+    return r
+
+
+def _rp(run):
+    return C.byref(run) if run is not None else None
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run=None, out=None):
     """y = conv2d(x, w).  With want_stats the result is (y, stats): stats = (mean, biased var) of y
     per output channel over (N, H, W) - what the BatchNorm that follows needs - taken from partials
-    the conv epilogue emits, or None where the library has no fused statistics for the shape."""
+    the conv epilogue emits, or None where the library has no fused statistics for the shape; bn_run
+    (a BnRunning) lets the kernel that finalises them also update that BatchNorm's running statistics.
+    out: optional [N, Cout, Ho, Wo] destination, may be a channel slice of a wider tensor (ASPP concat)."""
     _require(x, "x"); _require(w, "weight")
-    x = x.contiguous(); w = w.contiguous()
+    x = x.contiguous(); w = w if w.is_contiguous() else w.contiguous()
     d = _desc(x.shape, w.shape, stride, pad, dil)
-    y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
+    yns = 0
+    if out is None:
+        y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
+    else:
+        y = out
+        st = y.stride()
+        if tuple(y.shape) != (d.N, d.Cout, d.Hout, d.Wout) or st[3] != 1 or st[2] != d.Wout or st[1] != d.Hout * d.Wout:
+            raise RuntimeError("conv2d_fwd: out must be [N,Cout,Ho,Wo] with dense images (a channel slice is fine)")
+        yns = st[0]
     if bias is not None:
         _require(bias, "bias"); bias = bias.contiguous()
     L = _lib.lib()
-    ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), x.device)
+    ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD))
     if want_stats and bias is None:
-        slots = L.dcfp_conv2d_fwd_stat_slots(C.byref(d), _p(y), 0)
+        slots = L.dcfp_conv2d_fwd_stat_slots(C.byref(d), _p(y), yns)
         if slots > 0:
             part = _workspace("bn_stat_partials", slots * d.Cout * 2 * 4, x.device)
             _timed("conv_fwd", d, _conv_flops(d), lambda: check(
-                L.dcfp_conv2d_fwd_stats_f32_nchw(C.byref(d), _p(x), _p(w), _p(y), 0, _p(part), _p(ws),
-                                                 ws.numel(), _stream()), "conv2d_fwd_stats"))
+                L.dcfp_conv2d_fwd_stats_f32_nchw(C.byref(d), _p(x), _p(w), _p(y), yns, _p(part), _p(ws),
+                                                 ws.numel(), valid, _stream()), "conv2d_fwd_stats"))
             mv = torch.empty((2, d.Cout), dtype=torch.float32, device=x.device)
             check(L.dcfp_bn_stats_from_partials_f32(_p(part), slots, 128, d.Cout, _p(mv[0]), _p(mv[1]),
-                                                    _stream()), "bn_stats_from_partials")
-            return y, (mv[0], mv[1])
+                                                    _rp(bn_run), _stream()), "bn_stats_from_partials")
+            return y, (mv[0], mv[1], bn_run is not None)
     _timed("conv_fwd", d, _conv_flops(d), lambda: check(
-        L.dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), 0, _p(ws), ws.numel(),
+        L.dcfp_conv2d_fwd_f32_nchw(C.byref(d), _p(x), _p(w), _p(bias), _p(y), yns, _p(ws), ws.numel(), valid,
                                    _stream()), "conv2d_fwd"))
     return (y, None) if want_stats else y
 
@@ -150,7 +204,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
 def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
     """dx = conv_transpose(dy, w); with accumulate, `out` (+)= the result in place."""
     _require(dy, "dy")
-    w = w.contiguous()
+    w = w if w.is_contiguous() else w.contiguous()
     d = _desc(xshape, w.shape, stride, pad, dil)
     dy, ns = _batch_strided(dy)
     if out is not None:
@@ -161,14 +215,15 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
         dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
         accumulate = False
     L = _lib.lib()
-    ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_DGRAD), dy.device)
+    ws, valid = _wp_buffer(w, _lib.CONV_DGRAD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_DGRAD))
     _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
         L.dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), int(bool(accumulate)),
-                                     _p(ws), ws.numel(), _stream()), "conv2d_dgrad"))
+                                     _p(ws), ws.numel(), valid, _stream()), "conv2d_dgrad"))
     return dx
 
 
-def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False):
+def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=None):
+    """(dw, db); dw / db: optional destinations (the gradient arena's views)."""
     _require(dy, "dy"); _require(x, "x")
     x = x.contiguous()
     d = _desc(x.shape, wshape, stride, pad, dil)
@@ -176,11 +231,31 @@ def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False):
     L = _lib.lib()
     nbytes = L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_WGRAD)
     ws = _workspace("wgrad", nbytes, x.device)
-    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
-    db = torch.empty((wshape[0],), dtype=torch.float32, device=x.device) if need_bias else None
+    if dw is None:
+        dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+    elif tuple(dw.shape) != tuple(wshape) or not dw.is_contiguous():
+        raise RuntimeError("conv2d_wgrad: dw must be a contiguous tensor of the weight shape")
+    if need_bias and db is None:
+        db = torch.empty((wshape[0],), dtype=torch.float32, device=x.device)
     _timed("conv_wgrad", d, _conv_flops(d), lambda: check(
-        L.dcfp_conv2d_wgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(x), _p(dw), _p(db), _p(ws),
+        L.dcfp_conv2d_wgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(x), _p(dw), _p(db) if need_bias else None, _p(ws),
                                      ws.numel(), _stream()), "conv2d_wgrad"))
+    return dw, (db if need_bias else None)
+
+
+def add_into(dst, src):
+    """dst += src through the library (gradient accumulation onto an attached arena view)."""
+    check(_lib.lib().dcfp_add_f32(_p(dst), _p(src), _p(dst), dst.numel(), _stream()), "add")
+
+
+def wgrad_into_param(dy, x, w, bias, stride, pad, dil):
+    """Weight (and bias) gradient of a conv written where the parameter's gradient lives: returns
+    (dw, db) as the autograd Function should return them (None = already accumulated in .grad)."""
+    tw, kw = arena.grad_target(w)
+    tb, kb = arena.grad_target(bias) if bias is not None else (None, 0)
+    conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, dil, need_bias=bias is not None, dw=tw, db=tb)
+    dw = arena.grad_commit(w, tw, kw, add_into)
+    db = arena.grad_commit(bias, tb, kb, add_into) if bias is not None else None
     return dw, db
 
 
@@ -191,19 +266,21 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil):
         y = conv2d_fwd(x, w, bias, stride, pad, dil)
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.save_for_backward(x)
+        ctx.params = (w, bias)           # the Parameter objects: their gradient slots are looked up on them
+        ctx.cfg = (stride, pad, dil)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        stride, pad, dil, has_bias = ctx.cfg
+        (x,) = ctx.saved_tensors
+        w, bias = ctx.params
+        stride, pad, dil = ctx.cfg
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(dy, w, tuple(x.shape), stride, pad, dil)
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, dil, need_bias=has_bias)
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            dw, db = wgrad_into_param(dy, x, w, bias, stride, pad, dil)
         return dx, dw, db, None, None, None
 
 
@@ -212,7 +289,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
 
 
 # ------------------------------------------------------------- batch norm
-def bn_stats(x):
+def bn_stats(x, run=None):
     _require(x, "x")
     N, Cc, H, W = x.shape
     x, ns = _batch_strided(x)
@@ -221,21 +298,29 @@ def bn_stats(x):
     mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
     var = torch.empty(Cc, dtype=torch.float32, device=x.device)
     _timed("bn_stats", None, 4.0 * x.numel(), lambda: check(
-        L.dcfp_bn_stats_f32(_p(x), ns, N, Cc, H * W, _p(mean), _p(var), _p(ws), ws.numel(), _stream()),
+        L.dcfp_bn_stats_f32(_p(x), ns, N, Cc, H * W, _p(mean), _p(var), _rp(run), _p(ws), ws.numel(), _stream()),
         "bn_stats"))
     return mean, var
 
 
-def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False):
+def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False, out=None):
     N, Cc, H, W = x.shape
     x = x.contiguous()
     if residual is not None:
         residual = residual.contiguous()
-    y = torch.empty_like(x)
+    yns = 0
+    if out is None:
+        y = torch.empty_like(x)
+    else:           # e.g. a channel slice of the ASPP concat tensor (aspp.py:77)
+        y = out
+        st = y.stride()
+        if tuple(y.shape) != tuple(x.shape) or st[3] != 1 or st[2] != W or st[1] != H * W:
+            raise RuntimeError("bn_apply: out must have dense images")
+        yns = st[0]
     nbytes = (8.0 + (4.0 if residual is not None else 0.0)) * x.numel()
     _timed("bn_apply", None, nbytes, lambda: check(
         _lib.lib().dcfp_bn_apply_f32(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps),
-                                     _p(residual), int(relu), _p(y), 0, N, Cc, H * W, _stream()),
+                                     _p(residual), int(relu), _p(y), yns, N, Cc, H * W, _stream()),
         "bn_apply"))
     return y
 
@@ -261,19 +346,23 @@ def bn_apply_relu_mask(x, mean, var, gamma, beta, eps, residual):
     return y, mask
 
 
-def bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu):
+def bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu, dgamma=None, dbeta=None):
     """relu: 0 none, 1 mask from y, 2 mask re-derived from x (forward had no residual), 3 `y` is the
-    1-bit-per-element mask written by bn_apply_relu_mask."""
+    1-bit-per-element mask written by bn_apply_relu_mask.  Returns (sum_dy, sum_dy_xmu) adjacent in one
+    buffer, and dgamma; dgamma / dbeta (optional C-float destinations: the parameters' gradient slots)
+    receive sum_dy_xmu * istd and a copy of sum_dy."""
     N, Cc, H, W = x.shape
     dy, dns = _batch_strided(dy)
     L = _lib.lib()
     ws = _workspace("bn", L.dcfp_bn_workspace_bytes(N, Cc, H * W), x.device)
-    s = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
-    s1, s2, dgamma = s[0], s[1], s[2]
+    s = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    s1, s2 = s[0], s[1]
+    if dgamma is None:
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
     _timed("bn_bwd_reduce", None, (8.0 + (4.0 if relu == 1 else 0.125 if relu == 3 else 0.0)) * x.numel(), lambda: check(
         L.dcfp_bn_bwd_reduce_f32(_p(dy), dns, _p(x), _p(y) if relu in (1, 3) else None, 0, _p(mean), _p(var),
                                  _p(gamma), _p(beta), float(eps), int(relu), N, Cc, H * W, _p(s1), _p(s2),
-                                 _p(dgamma), _p(ws), ws.numel(), _stream()),
+                                 _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream()),
         "bn_bwd_reduce"))
     return s1, s2, dgamma
 
@@ -318,10 +407,32 @@ def _count_tensor(count, device):
     return t
 
 
-def sync_bn_stats(mean, var, count, group):
+def syncbn_combine_reference(allv, Cc):
+    """The pooled statistics of `world` gathered rows (mean[C], var[C], count) - the ONE formula both the
+    HIP kernel (syncbn_combine_kernel in csrc/bn.hip) and the host path below evaluate, in fp64 and in
+    rank order:  tot = sum n_r;  m = (sum mean_r n_r)/tot;  v = (sum (var_r + (mean_r - m)^2) n_r)/tot."""
+    a = allv.double()
+    world = a.shape[0]
+    n = a[:, 2 * Cc]
+    tot = torch.zeros((), dtype=torch.float64, device=a.device)
+    m = torch.zeros(Cc, dtype=torch.float64, device=a.device)
+    for r in range(world):
+        tot = tot + n[r]
+        m = m + a[r, :Cc] * n[r]
+    m = m / tot
+    v = torch.zeros(Cc, dtype=torch.float64, device=a.device)
+    for r in range(world):
+        dlt = a[r, :Cc] - m
+        v = v + (a[r, Cc:2 * Cc] + dlt * dlt) * n[r]
+    return m.float(), (v / tot).float(), tot.float().reshape(1)
+
+
+def sync_bn_stats(mean, var, count, group, run=None, running=None):
     """SyncBatchNorm forward exchange (engine.py:65): ONE all_gather of [mean, var, count]
     (2C+1 floats per rank), then the pooled mean / biased variance over all ranks' pixels
-    (parallel-variance combination), identical on every rank; the total count stays on the device."""
+    (parallel-variance combination), identical on every rank; the total count stays on the device.
+    run (device path) / running = (running_mean, running_var, momentum, nbt) (host path): the running
+    statistics are updated from the POOLED statistics, as nn.SyncBatchNorm does."""
     Cc = mean.numel()
     world = dist.get_world_size(group)
     local = torch.cat([mean, var, _count_tensor(count, mean.device)])
@@ -330,79 +441,125 @@ def sync_bn_stats(mean, var, count, group):
     if mean.is_cuda:
         out = torch.empty(2 * Cc + 1, device=mean.device, dtype=torch.float32)
         check(_lib.lib().dcfp_syncbn_combine_f32(_p(allv), world, Cc, _p(out), _p(out[Cc:]), _p(out[2 * Cc:]),
-                                                 _stream()), "syncbn_combine")
+                                                 _rp(run), _stream()), "syncbn_combine")
         return out[:Cc], out[Cc:2 * Cc], out[2 * Cc:]
-    # host tensors (the gloo rehearsal of the exchange in tests/test_distributed_cpu.py)
-    means, vars_, counts = allv[:, :Cc], allv[:, Cc:2 * Cc], allv[:, 2 * Cc:]
-    total = counts.sum()
-    gmean = (means * counts).sum(0) / total
-    gvar = ((vars_ + (means - gmean) ** 2) * counts).sum(0) / total
-    return gmean.contiguous(), gvar.contiguous(), total.reshape(1).contiguous()
+    # host tensors (the gloo tests): the same formula, evaluated by torch in fp64
+    gmean, gvar, total = syncbn_combine_reference(allv, Cc)
+    if running is not None:
+        rm, rv, momentum, nbt = running
+        if rm is not None and momentum is not None:
+            n = float(total)
+            rm.mul_(1.0 - momentum).add_(gmean, alpha=momentum)
+            rv.mul_(1.0 - momentum).add_(gvar * (n / max(n - 1.0, 1.0)), alpha=momentum)
+        if nbt is not None:
+            nbt.add_(1)
+    return gmean.contiguous(), gvar.contiguous(), total.contiguous()
 
 
-def sync_bn_bwd_sums(s1, s2, group):
+def sync_bn_bwd_sums(s1, s2, group, async_op=False):
     """SyncBatchNorm backward exchange: ONE all_reduce(SUM) of [sum g, sum g*(x-mean)] (2C floats);
-    bn_bwd_reduce returns the two rows adjacent in one buffer, which is then reduced in place."""
+    bn_bwd_reduce returns the two rows adjacent in one buffer, which is then reduced in place.
+    async_op: returns (s1, s2, work) with the exchange in flight on the collective's stream - the caller
+    enqueues independent kernels (a weight gradient) and calls work.wait() before it reads the sums."""
     Cc = s1.numel()
     if (s1.is_contiguous() and s2.is_contiguous() and s1.untyped_storage().data_ptr() == s2.untyped_storage().data_ptr()
             and s2.storage_offset() == s1.storage_offset() + Cc):
         both = s1.as_strided((2 * Cc,), (1,), s1.storage_offset())
-        dist.all_reduce(both, group=group)
-        return s1, s2
+        work = dist.all_reduce(both, group=group, async_op=async_op)
+        return (s1, s2, work) if async_op else (s1, s2)
     both = torch.cat([s1, s2])
-    dist.all_reduce(both, group=group)
-    return both[:Cc].contiguous(), both[Cc:].contiguous()
+    work = dist.all_reduce(both, group=group, async_op=async_op)
+    r1, r2 = both[:Cc], both[Cc:]
+    return (r1, r2, work) if async_op else (r1.contiguous(), r2.contiguous())
 
 
 def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, training,
-                    momentum, eps, sync, stats=None, want_mask=False):
+                    momentum, eps, sync, nbt=None, stats=None, want_mask=False, out=None):
     """Shared BN(+ReLU)(+residual) forward: returns (y, state) with state =
-    (mean, var, count, group) for the backward.  `stats` = this rank's (mean, biased var) when the
-    producing conv already emitted them (conv2d_fwd(..., want_stats=True))."""
+    (mean, var, count, group) for the backward.  `stats` = this rank's (mean, biased var, running-updated?)
+    when the producing conv already emitted them (conv2d_fwd(..., want_stats=True)).  nbt: the module's
+    num_batches_tracked buffer (incremented by the kernel that finalises the statistics)."""
     _require(x, "x")
     x = x.contiguous()
     N, Cc, H, W = x.shape
     count = float(N * H * W)
     group = _sync_group(sync) if training else None
     if training:
-        mean, var = stats if stats is not None else bn_stats(x)
+        run = _bn_run(running_mean, running_var, momentum, nbt)
+        if stats is not None:
+            mean, var, applied = stats
+            if applied:
+                run = None
+        elif group is None:
+            mean, var = bn_stats(x, run)
+            run = None
+        else:
+            mean, var = bn_stats(x)
         if group is not None:
-            mean, var, count = sync_bn_stats(mean, var, count, group)
-        if running_mean is not None and momentum is not None:
-            cdev = count if isinstance(count, torch.Tensor) else None
-            check(_lib.lib().dcfp_bn_update_running_f32(
-                _p(mean), _p(var), Cc, float(momentum), 0.0 if cdev is not None else float(count),
-                _p(cdev), _p(running_mean), _p(running_var), _stream()), "bn_update_running")
+            mean, var, count = sync_bn_stats(mean, var, count, group, run)
+        elif run is not None:     # statistics came from elsewhere without the bookkeeping
+            if running_mean is not None and momentum is not None:
+                check(_lib.lib().dcfp_bn_update_running_f32(
+                    _p(mean), _p(var), Cc, float(momentum), float(count), None, _p(running_mean),
+                    _p(running_var), _stream()), "bn_update_running")
+            if nbt is not None:
+                nbt.add_(1)
     else:
         mean, var = running_mean, running_var
-    if want_mask and relu and residual is not None and BN_RELU_BITMASK:
+    if want_mask and relu and residual is not None and BN_RELU_BITMASK and out is None:
         ym = bn_apply_relu_mask(x, mean, var, gamma, beta, eps, residual)
         if ym is not None:
             return ym[0], (mean, var, count, group, ym[1])
-    y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu)
+    y = bn_apply(x, mean, var, gamma, beta, eps, residual, relu, out=out)
     return y, (mean, var, count, group)
 
 
-def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res):
-    """Shared backward: returns (dx, dgamma, dbeta, dres).  dgamma/dbeta are this rank's sums
-    (the gradient all-reduce averages them); under SyncBN the sums entering dx are global.
-    `y` is only needed for the ReLU mask of a BN that had a residual input; otherwise the mask
-    is re-derived from x inside the kernels (pass y=None)."""
+def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None, bparam=None, eps=1e-5):
+    """First half of the BN backward: the two per-channel sums, dgamma / dbeta written to the parameters'
+    gradient slots, and (SyncBN) the exchange of the sums started asynchronously.  Returns a tuple for
+    bn_backward_apply; independent kernels enqueued between the two overlap the exchange."""
     mean, var, count, group = state[:4]
     mask = state[4] if len(state) > 4 else None
     if relu and mask is not None:      # residual BN whose forward kept the ReLU mask as bits
         relu, y = 3, mask
     else:
         relu = (1 if y is not None else 2) if relu else 0
-    s1, s2, dgamma = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu)
-    # the SyncBN exchange reduces (s1, s2) in place; dbeta stays this rank's sum
-    dbeta = s1.clone() if (training and group is not None) else s1
-    if training:
-        r1, r2 = sync_bn_bwd_sums(s1, s2, group) if group is not None else (s1, s2)
-    else:  # running statistics are constants: dx = g * gamma * istd
-        r1 = torch.zeros_like(s1); r2 = torch.zeros_like(s2)
-    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, r1, r2, count, relu, want_res)
+    gp = gparam if gparam is not None else gamma
+    bp = bparam if bparam is not None else beta
+    tg, kg = arena.grad_target(gp)
+    tb, kb = arena.grad_target(bp)
+    s1, s2, _ = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu, dgamma=tg, dbeta=tb)
+    dgamma = arena.grad_commit(gp, tg, kg, add_into)
+    dbeta = arena.grad_commit(bp, tb, kb, add_into)
+    work = None
+    if training and group is not None:
+        s1, s2, work = sync_bn_bwd_sums(s1, s2, group, async_op=True)
+    elif not training:   # running statistics are constants: dx = g * gamma * istd
+        s1 = torch.zeros_like(s1); s2 = torch.zeros_like(s2)
+    return (s1, s2, work, relu, y, dgamma, dbeta)
+
+
+def bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res):
+    s1, s2, work, relu, y, dgamma, dbeta = red
+    if work is not None:
+        work.wait()
+    mean, var, count = state[:3]
+    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_res)
     return dx, dgamma, dbeta, dres
+
+
+def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res, gparam=None, bparam=None,
+                     between=None):
+    """Shared backward: returns (dx, dgamma, dbeta, dres).  dgamma/dbeta are this rank's sums (None when
+    they went straight into the gradient arena; the gradient all-reduce averages them); under SyncBN the
+    sums entering dx are global.  `y` is only needed for the ReLU mask of a BN that had a residual input;
+    otherwise the mask is re-derived from x inside the kernels (pass y=None).  between: optional callable
+    run after the reduction (and the start of the SyncBN exchange) and before dx - independent work
+    that hides the exchange."""
+    red = bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam, bparam, eps)
+    mid = between() if between is not None else None
+    out = bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res)
+    return out + ((mid,) if between is not None else ())
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -414,26 +571,28 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, training,
-                momentum, eps, sync):
+                momentum, eps, sync, nbt):
         x = x.contiguous()
         y, state = bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu,
-                                   training, momentum, eps, sync)
+                                   training, momentum, eps, sync, nbt=nbt)
         mean, var, count, group = state[:4]
         # y is saved only where the ReLU mask cannot be re-derived from x (residual input)
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var, gamma, beta,
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var,
                               count if isinstance(count, torch.Tensor) else None)
+        ctx.params = (gamma, beta)
         ctx.cfg = (relu, training, eps, None if isinstance(count, torch.Tensor) else count, group,
                    residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, gamma, beta, count_t = ctx.saved_tensors
+        x, y, mean, var, count_t = ctx.saved_tensors
+        gamma, beta = ctx.params
         relu, training, eps, count, group, has_res = ctx.cfg
         state = (mean, var, count_t if count_t is not None else count, group)
         need_res = has_res and ctx.needs_input_grad[5]
         dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, need_res)
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 
 class BottleneckFn(torch.autograd.Function):
@@ -442,7 +601,9 @@ class BottleneckFn(torch.autograd.Function):
     1x1(stride)+BN downsample on the residual.  Same kernels as the op-level Functions; what the
     fusion buys is the backward: the block input receives two gradients (through conv1 and
     through the residual), and here conv1's dgrad ACCUMULATES into the residual gradient buffer
-    instead of autograd materialising both and adding them (33 full-size adds per step)."""
+    instead of autograd adding two full tensors (33 full-size adds per step); every weight / gamma / beta
+    gradient is written straight into the gradient arena; under SyncBN each weight gradient is enqueued
+    between a BatchNorm's reduction and its dx so that it hides the exchange of the sums."""
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
@@ -450,60 +611,97 @@ class BottleneckFn(torch.autograd.Function):
         x = x.contiguous()
         has_ds = len(tensors) == 12
         w1, g1, b1, w2, g2, b2, w3, g3, b3 = tensors[:9]
-        bnargs = cfg["bn"]   # per BN: (running_mean, running_var, training, momentum, eps, sync)
+        bnargs = cfg["bn"]   # per BN: (running_mean, running_var, training, momentum, eps, sync, nbt)
         stride, dil = cfg["stride"], cfg["dil"]
-        # (opt-in) each conv hands the batch statistics of its output to the BatchNorm behind it
-        fuse = FUSE_BN_STATS
+        fuse = FUSE_BN_STATS   # each conv hands the batch statistics of its output to the BatchNorm behind it
 
-        def conv_s(inp, wgt, st=1, pd=0, dl=1, want=False):
-            if want:
-                return conv2d_fwd(inp, wgt, None, st, pd, dl, want_stats=True)
-            return conv2d_fwd(inp, wgt, None, st, pd, dl), None
+        def conv_bn(inp, wgt, a, g, b, st=1, pd=0, dl=1, relu=True, res=None, want_mask=False):
+            rm, rv, training, momentum, eps, sync, nbt = a
+            stats = None
+            if fuse and training:
+                # the kernel finalising the statistics also does the running-stat bookkeeping, unless the
+                # statistics still have to be pooled over the ranks first (SyncBN)
+                run = _bn_run(rm, rv, momentum, nbt) if _sync_group(sync) is None else None
+                c, stats = conv2d_fwd(inp, wgt, None, st, pd, dl, want_stats=True, bn_run=run)
+            else:
+                c = conv2d_fwd(inp, wgt, None, st, pd, dl)
+            y, state = bn_forward_impl(c, g, b, rm, rv, res, relu, training, momentum, eps, sync, nbt=nbt,
+                                       stats=stats, want_mask=want_mask)
+            return c, y, state
 
-        c1, s1 = conv_s(x, w1, want=fuse and bnargs[0][2])
-        y1, st1 = bn_forward_impl(c1, g1, b1, bnargs[0][0], bnargs[0][1], None, True, *bnargs[0][2:], stats=s1)
-        c2, s2 = conv_s(y1, w2, stride, dil, dil, want=fuse and bnargs[1][2])
-        y2, st2 = bn_forward_impl(c2, g2, b2, bnargs[1][0], bnargs[1][1], None, True, *bnargs[1][2:], stats=s2)
-        c3, s3 = conv_s(y2, w3, want=fuse and bnargs[2][2])
+        c1, y1, st1 = conv_bn(x, w1, bnargs[0], g1, b1)
+        c2, y2, st2 = conv_bn(y1, w2, bnargs[1], g2, b2, stride, dil, dil)
         if has_ds:
             wd, gd, bd = tensors[9:]
-            cd, sd = conv_s(x, wd, stride, 0, 1, want=fuse and bnargs[3][2])
-            res, std = bn_forward_impl(cd, gd, bd, bnargs[3][0], bnargs[3][1], None, False, *bnargs[3][2:], stats=sd)
+            cd, res, std = conv_bn(x, wd, bnargs[3], gd, bd, stride, 0, 1, relu=False)
         else:
             cd, res, std = None, x, None
-        out, st3 = bn_forward_impl(c3, g3, b3, bnargs[2][0], bnargs[2][1], res, True, *bnargs[2][2:], stats=s3,
-                                   want_mask=True)
+        c3, out, st3 = conv_bn(y2, w3, bnargs[2], g3, b3, res=res, want_mask=True)
         ctx.has_ds = has_ds
         ctx.cfg = (stride, dil, [a[2] for a in bnargs], [a[4] for a in bnargs])
-        ctx.states = (st1, st2, st3, std)
-        ctx.save_for_backward(x, c1, y1, c2, y2, c3, out, cd, *tensors)
+        ctx.params = tensors
+        # per-BN backward state: tensors go through save_for_backward (version checks), the rest stays python
+        flat, meta = [], []
+        for st in (st1, st2, st3, std):
+            if st is None:
+                meta.append(None)
+                continue
+            mean, var, count, group = st[:4]
+            mask = st[4] if len(st) > 4 else None
+            meta.append((len(flat), isinstance(count, torch.Tensor), None if isinstance(count, torch.Tensor) else count,
+                         group, mask is not None))
+            flat += [mean, var] + ([count] if isinstance(count, torch.Tensor) else []) + ([mask] if mask is not None else [])
+        ctx.meta = meta
+        # with the 1-bit mask the block output is not needed by its own backward
+        keep_out = out if len(st3) <= 4 else None
+        ctx.save_for_backward(x, c1, y1, c2, y2, c3, keep_out, cd, *flat)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, c1, y1, c2, y2, c3, out, cd = ctx.saved_tensors[:8]
-        tensors = ctx.saved_tensors[8:]
+        flat = ctx.saved_tensors[8:]
+        tensors = ctx.params
         w1, g1, b1, w2, g2, b2, w3, g3, b3 = tensors[:9]
         stride, dil, training, eps = ctx.cfg
-        st1, st2, st3, std = ctx.states
+
+        def state(i):
+            m = ctx.meta[i]
+            if m is None:
+                return None
+            pos, count_is_t, count, group, has_mask = m
+            mean, var = flat[pos], flat[pos + 1]
+            pos += 2
+            if count_is_t:
+                count = flat[pos]; pos += 1
+            st = (mean, var, count, group)
+            return st + ((flat[pos],) if has_mask else ())
+        st1, st2, st3, std = state(0), state(1), state(2), state(3)
+
+        def wg(dy, inp, w, st=1, pd=0, dl=1):
+            return lambda: wgrad_into_param(dy, inp, w, None, st, pd, dl)[0]
+
         # bn3 (+residual, ReLU): gradient of conv3's output and of the residual branch
         d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], True)
         d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
-        dw3, _ = conv2d_wgrad(d_c3, y2, tuple(w3.shape), 1, 0, 1)
-        d_c2, dg2, db2, _ = bn_backward_impl(d_y2, c2, None, g2, b2, st2, True, training[1], eps[1], False)
+        # conv3's weight gradient does not feed bn2: it runs between bn2's reduction and its dx
+        d_c2, dg2, db2, _, dw3 = bn_backward_impl(d_y2, c2, None, g2, b2, st2, True, training[1], eps[1], False,
+                                                  between=wg(d_c3, y2, w3))
         d_y1 = conv2d_dgrad(d_c2, w2, tuple(y1.shape), stride, dil, dil)
-        dw2, _ = conv2d_wgrad(d_c2, y1, tuple(w2.shape), stride, dil, dil)
-        d_c1, dg1, db1, _ = bn_backward_impl(d_y1, c1, None, g1, b1, st1, True, training[0], eps[0], False)
-        dw1, _ = conv2d_wgrad(d_c1, x, tuple(w1.shape), 1, 0, 1)
-        grads = [dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3]
+        d_c1, dg1, db1, _, dw2 = bn_backward_impl(d_y1, c1, None, g1, b1, st1, True, training[0], eps[0], False,
+                                                  between=wg(d_c2, y1, w2, stride, dil, dil))
+        grads = [None, dg1, db1, dw2, dg2, db2, dw3, dg3, db3]
         if ctx.has_ds:
             wd, gd, bd = tensors[9:]
-            d_cd, dgd, dbd, _ = bn_backward_impl(d_res, cd, None, gd, bd, std, False, training[3], eps[3], False)
-            dwd, _ = conv2d_wgrad(d_cd, x, tuple(wd.shape), stride, 0, 1)
+            d_cd, dgd, dbd, _, dw1 = bn_backward_impl(d_res, cd, None, gd, bd, std, False, training[3], eps[3], False,
+                                                      between=wg(d_c1, x, w1))
+            dwd, _ = wgrad_into_param(d_cd, x, wd, None, stride, 0, 1)
             grads += [dwd, dgd, dbd]
             dx = conv2d_dgrad(d_cd, wd, tuple(x.shape), stride, 0, 1) if ctx.needs_input_grad[0] else None
         else:
+            dw1, _ = wgrad_into_param(d_c1, x, w1, None, 1, 0, 1)
             dx = d_res
+        grads[0] = dw1
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(d_c1, w1, tuple(x.shape), 1, 0, 1, out=dx, accumulate=True)
         else:
@@ -516,9 +714,121 @@ def bottleneck(x, cfg, tensors):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
-                   training=True, momentum=0.1, eps=1e-5, sync=False):
+                   training=True, momentum=0.1, eps=1e-5, sync=False, nbt=None):
     return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, relu,
-                                training, momentum, eps, sync)
+                                training, momentum, eps, sync, nbt)
+
+
+class AsppFn(torch.autograd.Function):
+    """The five ASPP branches and their concatenation (networks/tools/aspp.py:70-77) as ONE autograd node:
+    1x1 / three dilated 3x3 conv -> BN -> ReLU, and global mean -> 1x1 conv -> BN -> ReLU -> broadcast,
+    each writing its channel slice of the 1280-channel tensor directly (no torch.cat: the BN kernels take a
+    batch stride).  Backward: the branches read their slice of the incoming gradient in place and their
+    data gradients ACCUMULATE into one buffer through the dgrad epilogue (the reference's autograd adds
+    five 2048-channel tensors: 4 read-read-write passes over 1 GB each); each branch's weight gradient
+    runs between the next branch's BN reduction and its dx (hides the SyncBN exchange)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *tensors):
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        widths = [t.shape[0] for t in tensors[0::3]]
+        cat = torch.empty((N, sum(widths), H, W), dtype=torch.float32, device=x.device)
+        offs = [sum(widths[:k]) for k in range(5)]
+        states, cs = [], []
+        for k in range(4):
+            w, g, b = tensors[3 * k:3 * k + 3]
+            pad, dil = cfg["convs"][k]
+            rm, rv, training, momentum, eps, sync, nbt = cfg["bn"][k]
+            stats = None
+            if FUSE_BN_STATS and training:
+                run = _bn_run(rm, rv, momentum, nbt) if _sync_group(sync) is None else None
+                c, stats = conv2d_fwd(x, w, None, 1, pad, dil, want_stats=True, bn_run=run)
+            else:
+                c = conv2d_fwd(x, w, None, 1, pad, dil)
+            _, st = bn_forward_impl(c, g, b, rm, rv, None, True, training, momentum, eps, sync, nbt=nbt, stats=stats,
+                                    out=cat[:, offs[k]:offs[k] + widths[k]])
+            cs.append(c); states.append(st)
+        w5, g5, b5 = tensors[12:15]
+        rm, rv, training, momentum, eps, sync, nbt = cfg["bn"][4]
+        pooled = rowsum(x, 1.0 / (H * W))                           # AdaptiveAvgPool2d(1) (aspp.py:56)
+        c5 = conv2d_fwd(pooled, w5, None, 1, 0, 1)
+        y5, st5 = bn_forward_impl(c5, g5, b5, rm, rv, None, True, training, momentum, eps, sync, nbt=nbt)
+        broadcast_hw(y5, H, W, out=cat[:, offs[4]:offs[4] + widths[4]])   # bilinear 1x1 -> HxW (aspp.py:76)
+        states.append(st5)
+        ctx.cfg = (cfg["convs"], [a[2] for a in cfg["bn"]], [a[4] for a in cfg["bn"]], offs, widths)
+        ctx.params = tensors
+        flat, meta = [], []
+        for st in states:
+            mean, var, count, group = st[:4]
+            is_t = isinstance(count, torch.Tensor)
+            meta.append((len(flat), is_t, None if is_t else count, group))
+            flat += [mean, var] + ([count] if is_t else [])
+        ctx.meta = meta
+        ctx.save_for_backward(x, pooled, c5, *cs, *flat)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, pooled, c5 = ctx.saved_tensors[:3]
+        cs = ctx.saved_tensors[3:7]
+        flat = ctx.saved_tensors[7:]
+        tensors = ctx.params
+        convs, training, eps, offs, widths = ctx.cfg
+        N, Cin, H, W = x.shape
+
+        def state(i):
+            pos, is_t, count, group = ctx.meta[i]
+            return (flat[pos], flat[pos + 1], flat[pos + 2] if is_t else count, group)
+        need_dx = ctx.needs_input_grad[0]
+        grads = [None] * 15
+        dx = None
+        pending = None            # the previous branch's weight gradient, run inside the next BN backward
+        for k in range(4):
+            w, g, b = tensors[3 * k:3 * k + 3]
+            pad, dil = convs[k]
+            dslice = dcat[:, offs[k]:offs[k] + widths[k]]
+            res = bn_backward_impl(dslice, cs[k], None, g, b, state(k), True, training[k], eps[k], False,
+                                   between=pending)
+            d_c, grads[3 * k + 1], grads[3 * k + 2] = res[0], res[1], res[2]
+            if pending is not None:
+                grads[3 * (k - 1)] = res[4]
+            if need_dx:
+                dx = conv2d_dgrad(d_c, w, tuple(x.shape), 1, pad, dil, out=dx, accumulate=dx is not None)
+            pending = (lambda d_c=d_c, w=w, pad=pad, dil=dil: wgrad_into_param(d_c, x, w, None, 1, pad, dil)[0])
+        # image-pooling branch: broadcast^T = sum over pixels, then BN / 1x1 conv on N x C x 1 x 1
+        w5, g5, b5 = tensors[12:15]
+        g_y5 = rowsum(dcat[:, offs[4]:offs[4] + widths[4]], 1.0)
+        res = bn_backward_impl(g_y5, c5, None, g5, b5, state(4), True, training[4], eps[4], False, between=pending)
+        d_c5, grads[13], grads[14], grads[9] = res[0], res[1], res[2], res[4]
+        grads[12], _ = wgrad_into_param(d_c5, pooled, w5, None, 1, 0, 1)
+        if need_dx:
+            d_pooled = conv2d_dgrad(d_c5, w5, tuple(pooled.shape), 1, 0, 1)
+            dx = broadcast_hw(d_pooled, H, W, 1.0 / (H * W), out=dx, accumulate=dx is not None)   # mean^T
+        return (dx, None) + tuple(grads)
+
+
+def aspp_branches(x, cfg, tensors):
+    return AsppFn.apply(x, cfg, *tensors)
+
+
+class ForkFn(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (layer3's output feeds layer4 and the deep-supervision
+    head, networks/deeplabv3.py:44-50): the two incoming gradients are summed by dcfp_add_f32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        return add(ga, gb)
+
+
+def fork(x):
+    return ForkFn.apply(x) if (torch.is_grad_enabled() and x.requires_grad) else (x, x)
 
 
 # ---------------------------------------------------------------- pooling
@@ -562,12 +872,22 @@ def rowsum(x, scale):
     return y
 
 
-def broadcast_hw(v, H, W, scale=1.0):
+def broadcast_hw(v, H, W, scale=1.0, out=None, accumulate=False):
+    """y[n,c,:,:] (+)= scale * v[n,c]; out: optional destination with dense images (a channel slice)."""
     N, Cc = v.shape[0], v.shape[1]
     v = v.contiguous()
-    y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=v.device)
-    check(_lib.lib().dcfp_broadcast_hw_f32(_p(v), float(scale), _p(y), 0, 0, N, Cc, H * W, _stream()),
-          "broadcast_hw")
+    yns = 0
+    if out is None:
+        y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=v.device)
+        accumulate = False
+    else:
+        y = out
+        st = y.stride()
+        if tuple(y.shape) != (N, Cc, H, W) or st[3] != 1 or st[2] != W or st[1] != H * W:
+            raise RuntimeError("broadcast_hw: out must be [N,C,H,W] with dense images")
+        yns = st[0]
+    check(_lib.lib().dcfp_broadcast_hw_f32(_p(v), float(scale), _p(y), yns, int(bool(accumulate)), N, Cc, H * W,
+                                           _stream()), "broadcast_hw")
     return y
 
 
@@ -813,10 +1133,10 @@ def conv2d_fused_infer(x, w, scale, shift, stride=1, pad=0, dil=1, residual=None
         if tuple(residual.shape) != tuple(y.shape):
             raise RuntimeError("conv2d_fused_infer: residual shape mismatch")
     L = _lib.lib()
-    ws = _workspace("conv", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), x.device)
+    ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD))
     check(L.dcfp_conv2d_fwd_fused_f32_nchw(C.byref(d), _p(x), _p(w), _p(scale.contiguous()),
                                            _p(shift.contiguous()), _p(residual), int(bool(relu)), _p(y),
-                                           _p(ws), ws.numel(), _stream()), "conv2d_fwd_fused")
+                                           _p(ws), ws.numel(), valid, _stream()), "conv2d_fwd_fused")
     return y
 
 

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import SgdEntry, SGD_CHUNK, check
+from .arena import ParamArena
 
 
 def check_keywords_in_name(name, keywords=()):
@@ -34,26 +35,51 @@ def set_weight_decay(model, skip_list=(), skip_keywords=()):
 
 class FusedSGD(torch.optim.Optimizer):
     """SGD with momentum and weight decay (dampening 0, no nesterov):
-       g' = g + wd*p ; buf = g' (first step) | momentum*buf + g' ; p -= lr*buf."""
+       g' = g + wd*p ; buf = momentum*buf + g' (buf starts at 0, which makes the first step buf = g' exactly,
+       torch's clone) ; p -= lr*buf.
+
+    Parameters, gradients and momentum buffers live in three flat arenas (dcfp_amd/arena.py): addresses are
+    stable, so the device pointer table of a param group is built and uploaded ONCE (`table_rebuilds`
+    counts uploads) and a step is one kernel launch per non-empty group; `zero_grad()` launches nothing."""
 
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._tables = {}
+        self._arena = None
+        self.table_rebuilds = 0
+
+    def _all_params(self):
+        return [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+
+    def arena(self):
+        """The arena holding this optimizer's parameters, created on first use once they are on the GPU
+        (the reference builds the optimizer before `seg_model.to(device)`, train.py:212-219)."""
+        params = self._all_params()
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return None
+        if self._arena is None or not self._arena.covers(params):
+            self._arena = ParamArena.of(params)
+            self._tables = {}
+            for i, p in enumerate(self._arena.params):      # momentum restored before the arena existed
+                old = self.state[p].get("momentum_buffer") if p in self.state else None
+                view = self._arena.momentum_view(i)
+                if old is not None and old.data_ptr() != view.data_ptr():
+                    view.copy_(old)
+                self.state[p]["momentum_buffer"] = view
+        return self._arena
 
     def _table(self, gi, group, params):
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params) + (group["weight_decay"],)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr()) for p in params) \
+            + (group["weight_decay"],)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached[1], cached[2], cached[3]
-        self.table_rebuilds = getattr(self, "table_rebuilds", 0) + 1
+        self.table_rebuilds += 1
         entries = (SgdEntry * len(params))()
         chunk = 0
         for i, p in enumerate(params):
-            st = self.state[p]
-            if "momentum_buffer" not in st:
-                st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             e = entries[i]
-            e.param, e.grad, e.momentum_buf = p.data_ptr(), p.grad.data_ptr(), st["momentum_buffer"].data_ptr()
+            e.param, e.grad, e.momentum_buf = p.data_ptr(), p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr()
             e.n, e.first_chunk, e.weight_decay = p.numel(), chunk, group["weight_decay"]
             chunk += (p.numel() + SGD_CHUNK - 1) // SGD_CHUNK
         host = torch.frombuffer(bytearray(bytes(entries)), dtype=torch.uint8)
@@ -62,22 +88,20 @@ class FusedSGD(torch.optim.Optimizer):
         return dev, len(params), chunk
 
     def zero_grad(self, set_to_none: bool = True):
-        """Same contract as torch.optim.Optimizer.zero_grad; the in-place variant (what torch 1.10's
-        default did, train.py:256) zeroes all gradients with a few multi-tensor launches instead
-        of one fill per parameter."""
-        if set_to_none:
-            return super().zero_grad(set_to_none=True)
-        grads = []
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is not None:
-                    if p.grad.grad_fn is not None:
-                        p.grad.detach_()
-                    else:
-                        p.grad.requires_grad_(False)
-                    grads.append(p.grad)
-        if grads:
-            torch._foreach_zero_(grads)
+        """Same contract as torch.optim.Optimizer.zero_grad.  With the arena: set_to_none detaches the gradient
+        views (no launch; the next backward's first write overwrites), the in-place flavour (torch 1.10's
+        default, train.py:256) is ONE fill of the flat gradient buffer."""
+        ar = self.arena()
+        if ar is not None:
+            return ar.zero_grad(set_to_none)
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+        self._arena = None          # momentum buffers were replaced: re-adopt them into the arena on next use
+        from . import ops
+        ops.WEIGHT_EPOCH[0] += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -86,6 +110,7 @@ class FusedSGD(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        self.arena()
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
@@ -94,12 +119,12 @@ class FusedSGD(torch.optim.Optimizer):
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() \
                         or not p.grad.is_contiguous():
                     raise RuntimeError("FusedSGD: parameters and grads must be contiguous CUDA fp32")
-            first = int(not group.get("_stepped", False))
+                if "momentum_buffer" not in self.state[p]:     # parameter outside the arena
+                    self.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             table, n, chunks = self._table(gi, group, params)
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             check(L.dcfp_sgd_momentum_f32(C.c_void_p(table.data_ptr()), n, chunks, float(group["lr"]),
-                                          float(group["momentum"]), first, stream), "sgd_momentum")
-            group["_stepped"] = True
+                                          float(group["momentum"]), 0, stream), "sgd_momentum")
         from . import ops
         ops.WEIGHT_EPOCH[0] += 1
         return loss

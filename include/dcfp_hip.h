@@ -58,7 +58,11 @@ typedef struct DcfpConvDesc {
 enum { DCFP_CONV_FWD = 0, DCFP_CONV_DGRAD = 1, DCFP_CONV_WGRAD = 2 };
 
 /* Bytes of workspace a pass needs: fwd/dgrad — the permuted, zero-padded weight copy
- * Wp[tap][c][m] the kernel streams its A operand from; wgrad — the split-K slabs. */
+ * Wp[tap][c][m] the kernel streams its A operand from; wgrad — the split-K slabs.
+ * fwd/dgrad take `wp_valid`: 0 => the call (re)builds Wp in `workspace` first; != 0 => the caller
+ * vouches that `workspace` still holds the Wp an earlier call with the SAME descriptor, pass and
+ * weight values left there (weights change once per optimizer step, so a training loop keeps one
+ * buffer per conv and pass and permutes at most once per step). */
 size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass);
 
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
@@ -72,7 +76,7 @@ int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_
  * wider tensor (ASPP concat, aspp.py:77). */
 int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                              const float* bias, float* y, int64_t y_nstride,
-                             void* workspace, size_t workspace_bytes,
+                             void* workspace, size_t workspace_bytes, int wp_valid,
                              dcfp_stream_t stream);
 /* Inference path (evaluate.py:186-196 predict_whole): conv with the eval-mode BatchNorm folded
  * into the epilogue: y = act( conv(x,w)[co]*scale[co] + shift[co] (+ residual) ), act = ReLU if relu
@@ -80,12 +84,12 @@ int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float*
 int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
                                    const float* scale, const float* shift, const float* residual,
                                    int relu, float* y, void* workspace, size_t workspace_bytes,
-                                   dcfp_stream_t stream);
+                                   int wp_valid, dcfp_stream_t stream);
 /* dx = conv_transpose(dy, w); accumulate != 0 => dx += (fan-out gradients).
  * dy_nstride: batch stride of dy in elements (0 => dense). */
 int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
                                const float* w, float* dx, int accumulate,
-                               void* workspace, size_t workspace_bytes,
+                               void* workspace, size_t workspace_bytes, int wp_valid,
                                dcfp_stream_t stream);
 /* dw[co,ci,kh,kw] = sum_{n,p} dy[n,co,p] * x[n,ci,src(p,kh,kw)]; deterministic
  * two-stage split-K (no float atomics).  db (nullable) = sum_{n,p} dy. */
@@ -99,12 +103,23 @@ int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t d
  *   resnet.py:9,26-33,41-56; aspp.py:15-16,22-24; deeplabv3.py:26-31,38-39.
  * Statistics over (N,H,W) per channel; biased variance for normalisation.
  */
+/* Module-side bookkeeping of a training-mode nn.BatchNorm2d forward, folded into the kernel that
+ * finalises the statistics (resnet.py:9: momentum 0.1): when running_mean != NULL,
+ *   running = (1-momentum)*running + momentum*stat   (variance unbiased by count/(count-1)),
+ * and when num_batches_tracked != NULL (one int64) it is incremented by one. */
+typedef struct DcfpBnRunning {
+    float* running_mean;          /* nullable: no running-statistics update            */
+    float* running_var;
+    int64_t* num_batches_tracked; /* nullable                                          */
+    float momentum;
+    int32_t pad_;
+} DcfpBnRunning;
 /* Per-channel batch mean and biased variance of x[N,C,HW] (x_nstride elements
- * between images; 0 => C*HW).  workspace: dcfp_bn_workspace_bytes(N,C,HW). */
+ * between images; 0 => C*HW).  workspace: dcfp_bn_workspace_bytes(N,C,HW).  run: nullable. */
 size_t dcfp_bn_workspace_bytes(int N, int C, int HW);
 int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C, int HW,
-                      float* mean, float* var, void* workspace, size_t workspace_bytes,
-                      dcfp_stream_t stream);
+                      float* mean, float* var, const DcfpBnRunning* run,
+                      void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
 /* y = act( (x-mean)*rsqrt(var+eps)*gamma + beta (+ residual) ), act = ReLU if relu.
  * y_nstride: batch stride of y (0 => dense). */
 int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
@@ -124,6 +139,8 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
                            const float* var, const float* gamma, const float* beta, float eps,
                            int relu, int N, int C, int HW,
                            float* sum_dy, float* sum_dy_xmu, float* dgamma /* nullable: sum_dy_xmu*istd */,
+                           float* dbeta /* nullable: a second copy of sum_dy (the caller's gradient slot; sum_dy
+                                           itself may then be all-reduced in place under SyncBN) */,
                            void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
 /* Conv forward that also emits the BatchNorm batch statistics of its OUTPUT as partials
  * (resnet.py:25-33: every conv is followed by a BatchNorm that needs mean/var over N,H,W):
@@ -134,14 +151,16 @@ int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const float* x,
 int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride);
 int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y,
                                    int64_t y_nstride, float* stat_partials, void* workspace,
-                                   size_t workspace_bytes, dcfp_stream_t stream);
+                                   size_t workspace_bytes, int wp_valid, dcfp_stream_t stream);
 int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t slots, int slot_count, int C,
-                                    float* mean, float* var, dcfp_stream_t stream);
+                                    float* mean, float* var, const DcfpBnRunning* run /* nullable; count =
+                                    slots*slot_count */, dcfp_stream_t stream);
 /* SyncBatchNorm (engine.py:65) forward exchange, device side: `gathered` = world rows of
  * (mean[C], var[C], count) as all-gathered from the ranks -> pooled mean, biased variance over all
  * ranks' pixels and the total count (one float, stays on the device). */
 int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean, float* var,
-                            float* total_count, dcfp_stream_t stream);
+                            float* total_count, const DcfpBnRunning* run /* nullable; pooled statistics and
+                            count */, dcfp_stream_t stream);
 /* Running statistics of nn.BatchNorm2d in training mode (resnet.py:9, momentum 0.1):
  * running = (1-momentum)*running + momentum*stat, the variance unbiased by count/(count-1);
  * count_dev (nullable, one float) overrides `count` (SyncBN: global count on the device). */

@@ -24,7 +24,7 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(h, n), n
     assert sorted(_lib.SIGNATURES.keys()) == names
-    assert h.dcfp_abi_version() == 1
+    assert h.dcfp_abi_version() == 2
 
 
 def test_descriptor_errors_do_not_need_a_gpu():
@@ -32,10 +32,10 @@ def test_descriptor_errors_do_not_need_a_gpu():
     from dcfp_amd import _lib
     L = _lib.lib()
     d = _lib.ConvDesc(1, 8, 8, 8, 8, 5, 5, 1, 2, 1, 8, 8)          # 5x5 kernel: unsupported
-    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None, 0, None) == -2
+    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None, 0, 0, None) == -2
     d = _lib.ConvDesc(1, 8, 8, 8, 8, 3, 3, 1, 1, 1, 7, 8)          # wrong Hout
-    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None, 0, None) == -1
-    assert L.dcfp_bn_stats_f32(None, 0, 1, 1, 1, None, None, None, 0, None) == -1
+    assert L.dcfp_conv2d_fwd_f32_nchw(ctypes.byref(d), None, None, None, None, 0, None, 0, 0, None) == -1
+    assert L.dcfp_bn_stats_f32(None, 0, 1, 1, 1, None, None, None, None, 0, None) == -1
     assert L.dcfp_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
 
 

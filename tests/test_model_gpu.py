@@ -82,8 +82,8 @@ def test_forward_backward_vs_reference_golden(cuda, tag, model_name, backbone):
     rel = np.abs(mine - l64) / (np.abs(l64) + 1e-12)
     ref_rel = np.abs(l32 - l64) / (np.abs(l64) + 1e-12)
     # noise level of the reference itself: a tensor whose own fp32 error happens to be tiny is held to
-    # the 90th percentile of the reference's per-tensor errors, not to a fixed floor
-    noise = float(np.quantile(ref_rel, 0.9))
+    # the reference's WORST tensor (fp32 vs fp64 of the same code: 5e-3 simple, 2e-2 v3), not to a fixed floor
+    noise = float(ref_rel.max())
     bound = np.maximum(1e-3, 3 * np.maximum(ref_rel, noise))
     assert (rel <= bound).all(), [(pn[i], rel[i], ref_rel[i]) for i in np.argsort(-rel / bound)[:5]]
     # ... and through a fixed-cosine projection, which (unlike a norm) sees permuted / transposed gradients:
@@ -94,7 +94,7 @@ def test_forward_backward_vs_reference_golden(cuda, tag, model_name, backbone):
     p64, p32 = g["grad_proj:64"], g["grad_proj:32"]
     perr = np.abs(proj - p64) / (np.abs(l64) + 1e-12)
     pref = np.abs(p32 - p64) / (np.abs(l64) + 1e-12)
-    pnoise = float(np.quantile(pref, 0.9))
+    pnoise = float(pref.max())
     pbound = np.maximum(1e-3, 3 * np.maximum(pref, pnoise))
     assert (perr <= pbound).all(), [(pn[i], perr[i], pref[i]) for i in np.argsort(-perr / pbound)[:5]]
     for key in ("backbone.conv1.0", "backbone.layer1.0.conv1", "backbone.layer2.0.conv2", "last_conv.6"):

@@ -363,13 +363,25 @@ def test_syncbn_combine_kernel(cuda, world, C):
     gv = ((vars_.double() + (means.double() - gm) ** 2) * counts.double()[:, None]).sum(0) / tot
     dev_rows = rows.to(cuda)
     out = torch.empty(2 * C + 1, device=cuda)
+    rm = torch.randn(C, generator=g).to(cuda); rv = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    nbt = torch.tensor(3, dtype=torch.int64, device=cuda)
+    rm0, rv0 = rm.clone(), rv.clone()
+    run = ops._bn_run(rm, rv, 0.1, nbt)
     rc = _lib.lib().dcfp_syncbn_combine_f32(ops._p(dev_rows), world, C, ops._p(out), ops._p(out[C:]),
-                                            ops._p(out[2 * C:]), ops._stream())
+                                            ops._p(out[2 * C:]), ops._rp(run), ops._stream())
     assert rc == 0
     torch.cuda.synchronize()
     assert max_err(out[:C], gm) < 1e-6
     assert max_err(out[C:2 * C], gv) < 1e-6
     assert abs(out[2 * C].item() - tot.item()) < 1e-3
+    # the kernel and the host path evaluate ONE formula (ops.syncbn_combine_reference): bit-equal
+    rm_, rv_, tot_ = ops.syncbn_combine_reference(dev_rows, C)
+    assert torch.equal(out[:C], rm_) and torch.equal(out[C:2 * C], rv_) and torch.equal(out[2 * C:], tot_)
+    # running statistics from the POOLED statistics (nn.SyncBatchNorm), counter incremented on the device
+    n = tot.item()
+    assert max_err(rm, 0.9 * rm0.double() + 0.1 * gm.to(cuda)) < 1e-6
+    assert max_err(rv, 0.9 * rv0.double() + 0.1 * gv.to(cuda) * (n / (n - 1))) < 1e-6
+    assert nbt.item() == 4
 
 
 @pytest.mark.parametrize("Cout,k", [(256, 1), (128, 3), (64, 1), (512, 1), (256, 3)])
