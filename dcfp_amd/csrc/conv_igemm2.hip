@@ -12,36 +12,11 @@
 //  * MFMA operand fragments are double-buffered in registers (the ds_read for step kk+1 is
 //    issued before the 16 MFMAs of step kk), and the next tile's global loads / LDS stores are
 //    spread over the eight 16-MFMA slots of a K-step instead of forming one serial block.
-#include "common.h"
+#include "igemm2_common.h"
 #include <stdio.h>
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BK = 16;      // default K-step depth
-constexpr unsigned kOob = 0x80000000u;
-
-struct Igemm2Params {
-    const float* in;
-    const float* wp;    // permuted weights [T][CkP][Mpad]
-    const float* bias;
-    const float* scale;     // inference epilogue: y = act(acc*scale[m] + shift[m] (+ residual))
-    const float* shift;
-    const float* residual;  // same layout as out
-    int relu;
-    float* out;
-    long long in_nstride, out_nstride;
-    int N, M, Mpad, Ck, CkP;
-    int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
-    int sn, sd, off0, offstep;
-    int accumulate, vec_store;
-    int tile2d;         // igemm2_dma_kernel<9, true>: 0, or log2(columns) of a 2-D pixel tile (8 rows x 32 or 16 x 16)
-    float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
-};
 
 // Wp[t][c][m] = W[m*sAm + c*sAc + t]  (zero for c >= Ck or m >= M)
 __global__ void __launch_bounds__(256)
@@ -59,36 +34,6 @@ permute_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int 
         wp[i] = v;
     }
 }
-
-// compile-time loop: every index is a constant expression, so register arrays stay in registers
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int T>
-struct Frag;
-template <>
-struct Frag<4> {
-    static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    }
-};
-template <>
-struct Frag<2> {
-    static __device__ __forceinline__ void ld(const float* p, float (&f)[2]) {
-        const float2 v = *reinterpret_cast<const float2*>(p);
-        f[0] = v.x; f[1] = v.y;
-    }
-};
-template <>
-struct Frag<1> {
-    static __device__ __forceinline__ void ld(const float* p, float (&f)[1]) { f[0] = p[0]; }
-};
 
 // value of lane (l ^ MASK) within each 32-lane half (ds_swizzle bit-mask mode: and 0x1f, xor MASK)
 __device__ __forceinline__ float half_xor(float v, int mask) {

@@ -1,0 +1,290 @@
+// conv_igemm2p.hip — PERSISTENT variant of the 256 x 256-tile LDS-DMA kernel for 1x1 stride-1 convs
+// (forward of Bottleneck conv1/conv3 and their data gradients: networks/backbone/resnet.py:25-30).
+//
+// The one-tile-per-workgroup kernel (igemm2_dma_kernel<1,...> in conv_igemm2.hip) pays, per 256 x 256
+// tile, a cold first copy (global -> LDS latency with nothing to overlap) and an epilogue during which the
+// matrix pipe idles: 8.3 us per tile by a fit over the K = 256 and K = 1024 layers, i.e. 15 % of a
+// K = 256 tile (55 us).  Here a workgroup stays on its CU and walks tiles t = blockIdx.x, + gridDim.x, ...:
+//   * the first K-step of tile t+1 is copied into the free LDS buffer during the LAST K-step of tile t,
+//     so it has landed before the epilogue of t starts (its latency is covered by 128 MFMAs);
+//   * the epilogue's 64 stores per lane are issued and NOT waited for: they drain while tile t+1's first
+//     K-step computes (the store data registers are read at issue; the accumulators are re-zeroed
+//     afterwards), and that step's end-of-step vmcnt(0) retires them;
+//   * the BatchNorm-statistics merge has its own 66 KB of LDS (a workgroup owns the CU's 160 KB anyway:
+//     one wave per SIMD), so it no longer has to wait for the operand buffers to be idle.
+// Tile order, operand images, fragment reads, MFMA order and the statistics arithmetic are those of the
+// non-persistent kernel: results are bit-identical (tests/test_conv_large_gpu.py A/Bs the two builds
+// through DCFP_IGEMM_PERSIST).
+#include "igemm2_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((vector_size(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ u32x4 make_desc(const void* base, unsigned bytes) {   // raw buffer: stride 0, 32-bit data
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 d = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return d;
+}
+
+constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, M2) pairs
+
+template <bool ACC>
+__global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles) {
+    constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
+    float* Ss = smem + 2 * BK * (BM + BN);   // statistics scratch (only touched when p.stat_part)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int HiWi = p.Hi * p.Wi;
+    const int group = 8 * p.tiles_m;
+    const int nk = p.CkP / BK;
+
+    // wave w copies k-rows 4w .. 4w+3 of both operands
+    unsigned a_voff[4], b_row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a_voff[q] = (unsigned)((4 * wid + q) * p.Mpad) * 4u + lane * 16u;
+        b_row[q] = (unsigned)((4 * wid + q) * HiWi) * 4u;
+    }
+    const u32x4 a_desc = make_desc(p.wp, 0x7ffffffcu);
+    const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
+
+    // decode of a linear tile id: the same (pixel tile, M tile) order as the one-tile kernel, so that the
+    // workgroups of one XCD (equal blockIdx % 8 under round-robin placement) share pixel tiles in their L2
+    auto decode = [&](int t, int& nt, int& mt) {
+        const int g = t / group, local = t - g * group;
+        nt = g * 8 + (local & 7);
+        mt = local >> 3;
+    };
+    auto next_valid = [&](int t) {          // tiles past tiles_n_total in the last group are padding
+        while (t < total_tiles) {
+            int nt, mt;
+            decode(t, nt, mt);
+            if (nt < p.tiles_n_total) break;
+            t += gridDim.x;
+        }
+        return t;
+    };
+
+    // ---- loader state: the tile whose K-steps are being copied, and the next K-step of it
+    int ld_tile = next_valid(blockIdx.x), ld_cb = 0;
+    unsigned ld_as = 0, ld_boff4 = 0;
+    u32x4 ld_bdesc = a_desc;
+    auto ld_set_tile = [&]() {
+        int nt, mt;
+        decode(ld_tile, nt, mt);
+        const int img = nt / p.tiles_per_img;
+        const int p0 = (nt - img * p.tiles_per_img) * BN;
+        ld_as = (unsigned)(mt * BM) * 4u;
+        ld_bdesc = make_desc(p.in + (long long)img * p.in_nstride, (unsigned)(p.Ck * HiWi) * 4u);
+        const int pp = p0 + 4 * lane;                 // P % 4 == 0: a quad is inside or outside as a whole
+        ld_boff4 = pp < p.P ? (unsigned)pp * 4u : kOob;
+    };
+    auto issue = [&](int buf) {      // copy K-step ld_cb of tile ld_tile into LDS buffer `buf`, then step the loader
+        const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)(ld_cb * BK * p.Mpad) * 4u);
+        const unsigned b_cb = (unsigned)(ld_cb * BK * HiWi) * 4u;   // in the VGPR offset: the descriptor's bound
+        const unsigned b_s = 0;                                      // must see it (rows past Ck -> zeros)
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid + q) * BM) * 4u);
+            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BK + 4 * wid + q) * BN) * 4u);
+            const unsigned av = a_voff[q], as_ = a_s, bs_ = b_s;
+            const unsigned bv = ld_boff4 + b_row[q] + b_cb;
+            const u32x4 ad = a_desc, bd = ld_bdesc;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
+        });
+        if (++ld_cb == nk) {
+            ld_cb = 0;
+            ld_tile = next_valid(ld_tile + gridDim.x);
+            if (ld_tile < total_tiles) ld_set_tile();
+        }
+    };
+    auto retire = [&]() {   // every copy (and every older store) done, every fragment read done, then the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    int tile = ld_tile;
+    if (tile >= total_tiles) return;          // block-uniform
+    ld_set_tile();
+    int cur = 0;
+    issue(cur);
+    retire();
+    const int a_off = wm * (TM * 32) + TM * l31;
+    const int b_off = wn * (TN * 32) + TN * l31;
+
+    while (tile < total_tiles) {
+        int nt, mt;
+        decode(tile, nt, mt);
+        const int img = nt / p.tiles_per_img;
+        const int p0 = (nt - img * p.tiles_per_img) * BN;
+        const int m0 = mt * BM;
+        const int next_tile = next_valid(tile + gridDim.x);
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            // the loader runs one K-step ahead - across the tile boundary too
+            if (kt + 1 < nk || next_tile < total_tiles) issue(cur ^ 1);
+            const float* a = As + cur * (BK * BM) + a_off + lhi * BM;
+            const float* b = Bs + cur * (BK * BN) + b_off + lhi * BN;
+            float af[2][TM], bf[2][TN];
+            Frag<TM>::ld(a, af[0]);
+            Frag<TN>::ld(b, bf[0]);
+            static_for<0, BK / 2>([&](auto kk_) {
+                constexpr int kk = decltype(kk_)::value;
+                constexpr int fc = kk & 1;
+                if constexpr (kk + 1 < BK / 2) {
+                    Frag<TM>::ld(a + (2 * kk + 2) * BM, af[fc ^ 1]);
+                    Frag<TN>::ld(b + (2 * kk + 2) * BN, bf[fc ^ 1]);
+                }
+                static_for<0, TM>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    static_for<0, TN>([&](auto j_) {
+                        constexpr int j = decltype(j_)::value;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fc][i], bf[fc][j], acc[i][j], 0, 0, 0);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            retire();
+            cur ^= 1;
+        }
+
+        // ---- epilogue of this tile (the next tile's first K-step is already in LDS buffer `cur`)
+        float* o_img = p.out + (long long)img * p.out_nstride;
+        if (m0 + BM > p.M || p0 + BN > p.P) {     // edge tile (block-uniform): predicated stores
+            int pix = p0 + wn * (TN * 32) + TN * l31;
+            asm volatile("" : "+v"(pix));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int m = m0 + wm * (TM * 32) + TM * row + i;
+                    if (m >= p.M || pix >= p.P) continue;      // P % 4 == 0: the lane's 4 pixels are in or out together
+                    float* dst = o_img + (long long)m * p.P + pix;
+                    f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if constexpr (ACC) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            }
+        } else {
+            if constexpr (!ACC) {
+                if (p.stat_part) {
+                    // BatchNorm statistics of this tile's rows: see igemm2_dma_kernel (same arithmetic, same order)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2* st = reinterpret_cast<f32x2*>(Ss) + wid * (64 * 33);
+                    float* sp = p.stat_part + ((long long)(nt * WN + wn) * p.M + m0 + wm * (TM * 32)) * 2;
+                    static_for<0, 2>([&](auto h_) {
+                        constexpr int half = decltype(h_)::value;
+                        static_for<0, 2>([&](auto ii_) {
+                            constexpr int ii = decltype(ii_)::value;
+                            constexpr int i = 2 * half + ii;
+                            static_for<0, 16>([&](auto r_) {
+                                constexpr int r = decltype(r_)::value;
+                                const float a0 = acc[i][0][r], a1 = acc[i][1][r], a2 = acc[i][2][r], a3 = acc[i][3][r];
+                                const float s4 = (a0 + a1) + (a2 + a3);
+                                const float mu = 0.25f * s4;
+                                const float d0 = a0 - mu, d1 = a1 - mu, d2 = a2 - mu, d3 = a3 - mu;
+                                f32x2 v = {s4, (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)};
+                                st[(lhi * 32 + ii * 16 + r) * 33 + l31] = v;
+                            });
+                        });
+                        float sv[32], S = 0.f, M2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) {
+                            const f32x2 v = st[lane * 33 + k];
+                            sv[k] = v.x; S += v.x; M2 += v.y;
+                        }
+                        const float mean = S * (1.0f / 128.0f);
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) {
+                            const float d = 0.25f * sv[k] - mean;
+                            M2 += 4.0f * d * d;
+                        }
+                        const int rr = lane & 15;
+                        const int row = 16 * (lane >> 5) + 4 * (rr & 3) + 32 * (rr >> 2) + 2 * half + ((lane >> 4) & 1);
+                        sp[row * 2] = mean;
+                        sp[row * 2 + 1] = M2;
+                    });
+                }
+            }
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                o_img + (long long)m0 * p.P + p0, 0, 0x7ffffffcu, 0x00020000);
+            unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
+            asm volatile("" : "+v"(voff));
+            const unsigned P4 = (unsigned)p.P * 4u;
+            static_for<0, TM>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                f32x4 old[16];
+                if constexpr (ACC) {
+                    static_for<0, 16>([&](auto r_) {
+                        constexpr int r = decltype(r_)::value;
+                        constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                        old[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            o_rsrc, voff, (unsigned)row * P4, 0));
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                static_for<0, 16>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                    f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if constexpr (ACC) v += old[r];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                        __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                        o_rsrc, voff + (unsigned)row * P4, 0, 0);   // row offset in the VGPR: see igemm2_kernel
+                });
+                if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        tile = next_tile;
+    }
+}
+
+}  // namespace
+
+// Launch over all tiles of the problem described by `p` (filled by dcfp_igemm2_run).  One workgroup per CU.
+int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    const long long groups = ((long long)p.tiles_n_total + 7) / 8;
+    const long long total = groups * 8 * p.tiles_m;
+    if (total > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    long long blocks = total < cus ? total : cus;
+    blocks = blocks / 8 * 8;                       // grid % 8 == 0 keeps a workgroup's tiles on one pixel-tile residue
+    if (blocks < 8) blocks = total < 8 ? total : 8;
+    const size_t lds = (size_t)(2 * BK * 512 + (p.stat_part ? kStatFloats : 0)) * sizeof(float);
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, (int)total);
+        DCFP_RETURN_LAUNCH();
+    };
+    return p.accumulate ? launch(igemm2_dma1p_kernel<true>) : launch(igemm2_dma1p_kernel<false>);
+}

@@ -1,0 +1,63 @@
+// igemm2_common.h — types shared by the implicit-GEMM conv kernels (conv_igemm2.hip and the persistent
+// 1x1 LDS-DMA kernel in conv_igemm2p.hip).
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;      // default K-step depth
+constexpr unsigned kOob = 0x80000000u;
+
+struct Igemm2Params {
+    const float* in;
+    const float* wp;    // permuted weights [T][CkP][Mpad]
+    const float* bias;
+    const float* scale;     // inference epilogue: y = act(acc*scale[m] + shift[m] (+ residual))
+    const float* shift;
+    const float* residual;  // same layout as out
+    int relu;
+    float* out;
+    long long in_nstride, out_nstride;
+    int N, M, Mpad, Ck, CkP;
+    int Hi, Wi, Ho, Wo, P, tiles_per_img, tiles_n_total, tiles_m;
+    int sn, sd, off0, offstep;
+    int accumulate, vec_store;
+    int tile2d;         // igemm2_dma_kernel<9, true>: 0, or log2(columns) of a 2-D pixel tile (8 rows x 32 or 16 x 16)
+    float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
+};
+
+// compile-time loop: every index is a constant expression, so register arrays stay in registers
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int T>
+struct Frag;
+template <>
+struct Frag<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+};
+template <>
+struct Frag<2> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[2]) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        f[0] = v.x; f[1] = v.y;
+    }
+};
+template <>
+struct Frag<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[1]) { f[0] = p[0]; }
+};
+
+}  // namespace

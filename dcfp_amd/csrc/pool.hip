@@ -43,6 +43,51 @@ maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
     }
 }
 
+// Four consecutive outputs of one output row per thread (W % 8 == 0, so Wout = W/2 is a multiple of 4):
+// per input row two 16-byte loads (columns 2*ow0 .. 2*ow0+7) and one scalar (column 2*ow0-1, the previous
+// thread's last element: an L1 hit), 16-byte stores of values and argmax.  One block = one output row
+// segment, so consecutive blocks re-read the shared input row while it is still in L2.  The compare
+// sequence per output is the scalar kernel's (rows top to bottom, columns left to right, first maximum
+// wins, NaN propagates): results are bit-identical.
+__global__ void __launch_bounds__(kThreads)
+maxpool3x3s2_fwd_vec4_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ argmax,
+                             int H, int W, int Hout, int Wout, int segs) {
+    const long long rowid = blockIdx.x / segs;              // plane * Hout + oh
+    const int seg = blockIdx.x - (int)(rowid * segs);
+    const long long plane = rowid / Hout;
+    const int oh = (int)(rowid - plane * Hout);
+    const int ow0 = 4 * (seg * kThreads + threadIdx.x);
+    if (ow0 >= Wout) return;
+    const float* xp = x + plane * (long long)H * W;
+    const int h0 = 2 * oh - 1, c0 = 2 * ow0;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int hs = h0 < 0 ? 0 : h0;
+    int bi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bi[j] = hs * W + ((c0 + 2 * j - 1) < 0 ? 0 : (c0 + 2 * j - 1));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int h = h0 + r;
+        if (h < 0 || h >= H) continue;                      // block-uniform
+        const float* row = xp + (long long)h * W;
+        const float4 a = *reinterpret_cast<const float4*>(row + c0);
+        const float4 b = *reinterpret_cast<const float4*>(row + c0 + 4);
+        const float v[9] = {c0 > 0 ? row[c0 - 1] : 0.f, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k == 0 && j == 0 && c0 == 0) continue;  // left padding column
+                const float t = v[2 * j + k];
+                if (t > best[j] || t != t) { best[j] = t; bi[j] = h * W + c0 + 2 * j + k - 1; }
+            }
+        }
+    }
+    const long long o = rowid * Wout + ow0;
+    *reinterpret_cast<float4*>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<int4*>(argmax + o) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+}
+
 // Gather form of the backward: every input pixel looks at the (at most 4) windows
 // that contain it — deterministic, no atomics.
 __global__ void __launch_bounds__(kThreads)
@@ -214,8 +259,15 @@ extern "C" int dcfp_maxpool3x3s2_fwd_f32(const float* x, float* y, int32_t* argm
     if (Hout != (H + 2 - 3) / 2 + 1 || Wout != (W + 2 - 3) / 2 + 1) return DCFP_E_BADDESC;
     if ((long long)H * W > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const long long total = (long long)N * C * Hout * Wout;
-    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(stream_grid(total)), dim3(kThreads), 0,
-                       dcfp_s(stream), x, y, argmax, total, H, W, Hout, Wout);
+    const long long orows = (long long)N * C * Hout;
+    const int segs = (Wout / 4 + kThreads - 1) / kThreads;
+    if (W % 8 == 0 && dcfp_aligned16(x) && dcfp_aligned16(y) && dcfp_aligned16(argmax) &&
+        orows * segs <= 0x7fffffffLL)
+        hipLaunchKernelGGL(maxpool3x3s2_fwd_vec4_kernel, dim3((unsigned)(orows * segs)), dim3(kThreads), 0,
+                           dcfp_s(stream), x, y, argmax, H, W, Hout, Wout, segs);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(stream_grid(total)), dim3(kThreads), 0,
+                           dcfp_s(stream), x, y, argmax, total, H, W, Hout, Wout);
     DCFP_RETURN_LAUNCH();
 }
 

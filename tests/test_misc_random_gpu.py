@@ -90,7 +90,8 @@ def test_random_upsample_ce(cuda, case):
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 7, 9), (2, 64, 33, 47), (3, 17, 2, 2), (1, 5, 64, 1),
-                                   (2, 5, 9, 12), (1, 3, 6, 1028), (2, 4, 16, 4)])   # W % 4 == 0: the 4-column backward
+                                   (2, 5, 9, 12), (1, 3, 6, 1028), (2, 4, 16, 4),    # W % 4 == 0: the 4-column backward
+                                   (2, 3, 8, 8), (1, 2, 7, 2056), (1, 4, 5, 16), (3, 2, 1, 24)])   # W % 8 == 0: the 4-output forward
 def test_random_maxpool(cuda, shape):
     from dcfp_amd import ops
     g = torch.Generator().manual_seed(3)
