@@ -760,6 +760,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+// implemented in conv_igemm2p.hip: the persistent 1x1 LDS-DMA kernel
+int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream);
+
 // ---- entry points used by conv_igemm.hip's C-ABI functions
 size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
     const TileCfg c = pick_cfg(M, px, sd);
@@ -847,7 +850,11 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
             DCFP_RETURN_LAUNCH();
         };
-        if (T == 1) return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
+        if (T == 1) {
+            static const bool persist = [] { const char* e = getenv("DCFP_IGEMM_PERSIST"); return !e || atoi(e) != 0; }();   // =0: one tile per workgroup
+            if (persist) return dcfp_igemm2p_launch(p, stream);
+            return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
+        }
         if (((off0 | offstep) & 3) == 0)
             return accumulate ? launch(igemm2_dma_kernel<9, false, true>) : launch(igemm2_dma_kernel<9, false, false>);
         return accumulate ? launch(igemm2_dma_kernel<9, true, true>) : launch(igemm2_dma_kernel<9, true, false>);

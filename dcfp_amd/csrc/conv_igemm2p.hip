@@ -13,8 +13,21 @@
 //   * the BatchNorm-statistics merge has its own 66 KB of LDS (a workgroup owns the CU's 160 KB anyway:
 //     one wave per SIMD), so it no longer has to wait for the operand buffers to be idle.
 // Tile order, operand images, fragment reads, MFMA order and the statistics arithmetic are those of the
-// non-persistent kernel: results are bit-identical (tests/test_conv_large_gpu.py A/Bs the two builds
-// through DCFP_IGEMM_PERSIST).
+// non-persistent kernel: results are bit-identical (tests/test_conv_large_gpu.py compares the two through
+// DCFP_IGEMM_PERSIST).
+//
+// Measured on MI355X (tools/ab_p.sh, same box, 20 launches each; profiles/r02_persist_ab.txt):
+//   256->1024 @4x128x256 (K = 256) forward 116.1 -> 121.5 TF, its M = 1024 dgrad 120.8 -> 128.7 TF;
+//   K = 1024 shapes 136 -> 137.5 TF; 512->2048 134.7 -> 137.3 TF.
+// What the per-tile remainder is (debug build, -DDCFP_P_DEBUG): without the epilogue stores a K = 256 tile
+// takes 64.6 us, with them 71.7 us on 256 CUs but 65.1 / 64.2 us when only 128 / 64 workgroups run - the
+// stores are free until the WHOLE chip bursts 64 MB at once (equal tiles keep the CUs in lockstep).
+// Staggering the workgroups' start by 1..6 us per phase group (8 groups) gave back exactly what the idle
+// time cost (0.563 -> 0.570..0.579 ms); issuing the 8 copies of a K-step one per 16-MFMA sub-step instead
+// of back to back: no gain (the runtime "is there a next step" test becomes a branch per piece).
+// Register note: every loop-carried lane value must stay in registers - a spill reload is a VMEM operation
+// the compiler tracks, and its conservative vmcnt(N) waits in front of the next copies then also wait for
+// the (untracked, inline-asm) LDS-DMA copies in flight: the first version of this kernel lost 12 % to that.
 #include "igemm2_common.h"
 #include <stdlib.h>
 
@@ -32,7 +45,7 @@ __device__ __forceinline__ u32x4 make_desc(const void* base, unsigned bytes) {  
 constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, M2) pairs
 
 template <bool ACC>
-__global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles) {
+__global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles, int dbg) {
     constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BK][BM]
@@ -46,13 +59,10 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
     const int group = 8 * p.tiles_m;
     const int nk = p.CkP / BK;
 
-    // wave w copies k-rows 4w .. 4w+3 of both operands
-    unsigned a_voff[4], b_row[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        a_voff[q] = (unsigned)((4 * wid + q) * p.Mpad) * 4u + lane * 16u;
-        b_row[q] = (unsigned)((4 * wid + q) * HiWi) * 4u;
-    }
+    // wave w copies k-rows 4w .. 4w+3 of both operands: row offsets are wave-uniform (kept out of the VGPR
+    // file: nothing loop-carried may spill), the lane part is lane * 16 for A and the pixel quad for B
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    const unsigned lane16 = lane * 16u;
     const u32x4 a_desc = make_desc(p.wp, 0x7ffffffcu);
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
 
@@ -87,27 +97,38 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
         const int pp = p0 + 4 * lane;                 // P % 4 == 0: a quad is inside or outside as a whole
         ld_boff4 = pp < p.P ? (unsigned)pp * 4u : kOob;
     };
-    auto issue = [&](int buf) {      // copy K-step ld_cb of tile ld_tile into LDS buffer `buf`, then step the loader
-        const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)(ld_cb * BK * p.Mpad) * 4u);
-        const unsigned b_cb = (unsigned)(ld_cb * BK * HiWi) * 4u;   // in the VGPR offset: the descriptor's bound
-        const unsigned b_s = 0;                                      // must see it (rows past Ck -> zeros)
-        static_for<0, 4>([&](auto q_) {
-            constexpr int q = decltype(q_)::value;
-            const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid + q) * BM) * 4u);
-            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BK + 4 * wid + q) * BN) * 4u);
-            const unsigned av = a_voff[q], as_ = a_s, bs_ = b_s;
-            const unsigned bv = ld_boff4 + b_row[q] + b_cb;
-            const u32x4 ad = a_desc, bd = ld_bdesc;
+    // one of the 8 copies of a K-step: piece 2q = k-row 4w+q of A, piece 2q+1 = the same row of B
+    auto issue_piece = [&](int buf, auto piece_) {
+        constexpr int piece = decltype(piece_)::value;
+        constexpr int q = piece >> 1;
+        if constexpr ((piece & 1) == 0) {
+            const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)((ld_cb * BK + 4 * wid_s + q) * p.Mpad) * 4u);
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid_s + q) * BM) * 4u);
+            const unsigned av = lane16;
+            const u32x4 ad = a_desc;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory", "m0");
+                         :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+        } else {
+            // channel-row offset in the VGPR offset: the descriptor's bound must see it (rows past Ck -> zeros)
+            const unsigned b_cb = (unsigned)__builtin_amdgcn_readfirstlane((ld_cb * BK + 4 * wid_s + q) * HiWi) * 4u;
+            const unsigned b_s = 0;
+            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BK + 4 * wid_s + q) * BN) * 4u);
+            const unsigned bv = ld_boff4 + b_cb;
+            const u32x4 bd = ld_bdesc;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
-        });
+                         :: "s"(lb), "v"(bv), "s"(bd), "s"(b_s) : "memory", "m0");
+        }
+    };
+    auto ld_advance = [&]() {        // after the 8 pieces of a K-step: step the loader (and cross the tile boundary)
         if (++ld_cb == nk) {
             ld_cb = 0;
             ld_tile = next_valid(ld_tile + gridDim.x);
             if (ld_tile < total_tiles) ld_set_tile();
         }
+    };
+    auto issue = [&](int buf) {      // copy K-step ld_cb of tile ld_tile into LDS buffer `buf`, then step the loader
+        static_for<0, 8>([&](auto piece_) { issue_piece(buf, piece_); });
+        ld_advance();
     };
     auto retire = [&]() {   // every copy (and every older store) done, every fragment read done, then the barrier
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -116,6 +137,12 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
 
     int tile = ld_tile;
     if (tile >= total_tiles) return;          // block-uniform
+#ifdef DCFP_P_DEBUG
+    if (dbg & 0xff00) {                        // stagger: phase group (blockIdx / 8) % 8 waits g * dbg[15:8] * 64 x 64 clocks
+        const int g = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < g * ((dbg >> 8) & 0xff); ++i) __builtin_amdgcn_s_sleep(31);   // ~1 us each
+    }
+#endif
     ld_set_tile();
     int cur = 0;
     issue(cur);
@@ -141,7 +168,8 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
 
         for (int kt = 0; kt < nk; ++kt) {
             // the loader runs one K-step ahead - across the tile boundary too
-            if (kt + 1 < nk || next_tile < total_tiles) issue(cur ^ 1);
+            const bool more = kt + 1 < nk || next_tile < total_tiles;
+            if (more) issue(cur ^ 1);
             const float* a = As + cur * (BK * BM) + a_off + lhi * BM;
             const float* b = Bs + cur * (BK * BN) + b_off + lhi * BN;
             float af[2][TM], bf[2][TN];
@@ -169,6 +197,13 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
 
         // ---- epilogue of this tile (the next tile's first K-step is already in LDS buffer `cur`)
         float* o_img = p.out + (long long)img * p.out_nstride;
+#ifdef DCFP_P_DEBUG
+        if (dbg & 1) {                          // no stores at all (invalid results: timing decomposition only)
+            if (acc[0][0][0] == 123.456f) o_img[0] = 1.f;
+            tile = next_tile;
+            continue;
+        }
+#endif
         if (m0 + BM > p.M || p0 + BN > p.P) {     // edge tile (block-uniform): predicated stores
             int pix = p0 + wn * (TN * 32) + TN * l31;
             asm volatile("" : "+v"(pix));
@@ -207,16 +242,20 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
                                 st[(lhi * 32 + ii * 16 + r) * 33 + l31] = v;
                             });
                         });
-                        float sv[32], S = 0.f, M2 = 0.f;
+                        // (two sweeps over the row's 32 partials instead of holding them in 32 registers: the
+                        // persistent loop keeps more state live across the epilogue and must not spill - a spill
+                        // reload is a VMEM op the compiler then waits for in front of the next copies)
+                        float S = 0.f, M2 = 0.f;
 #pragma unroll
                         for (int k = 0; k < 32; ++k) {
                             const f32x2 v = st[lane * 33 + k];
-                            sv[k] = v.x; S += v.x; M2 += v.y;
+                            S += v.x; M2 += v.y;
                         }
                         const float mean = S * (1.0f / 128.0f);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int k = 0; k < 32; ++k) {
-                            const float d = 0.25f * sv[k] - mean;
+                            const float d = 0.25f * st[lane * 33 + k].x - mean;
                             M2 += 4.0f * d * d;
                         }
                         const int rr = lane & 15;
@@ -276,6 +315,11 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
     const long long total = groups * 8 * p.tiles_m;
     if (total > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     long long blocks = total < cus ? total : cus;
+    int dbg = 0;
+#ifdef DCFP_P_DEBUG
+    if (const char* e = getenv("DCFP_DBG_P_BLOCKS")) blocks = atoll(e) < blocks ? atoll(e) : blocks;
+    if (const char* e = getenv("DCFP_DBG_P")) dbg = atoi(e);
+#endif
     blocks = blocks / 8 * 8;                       // grid % 8 == 0 keeps a workgroup's tiles on one pixel-tile residue
     if (blocks < 8) blocks = total < 8 ? total : 8;
     const size_t lds = (size_t)(2 * BK * 512 + (p.stat_part ? kStatFloats : 0)) * sizeof(float);
@@ -283,7 +327,7 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, (int)total);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, (int)total, dbg);
         DCFP_RETURN_LAUNCH();
     };
     return p.accumulate ? launch(igemm2_dma1p_kernel<true>) : launch(igemm2_dma1p_kernel<false>);

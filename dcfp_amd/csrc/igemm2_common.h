@@ -4,14 +4,7 @@
 #include "common.h"
 #include <type_traits>
 
-namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BK = 16;      // default K-step depth
-constexpr unsigned kOob = 0x80000000u;
-
+// (global scope: passed between translation units)
 struct Igemm2Params {
     const float* in;
     const float* wp;    // permuted weights [T][CkP][Mpad]
@@ -29,6 +22,14 @@ struct Igemm2Params {
     int tile2d;         // igemm2_dma_kernel<9, true>: 0, or log2(columns) of a 2-D pixel tile (8 rows x 32 or 16 x 16)
     float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
 };
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;      // default K-step depth
+constexpr unsigned kOob = 0x80000000u;
 
 // compile-time loop: every index is a constant expression, so register arrays stay in registers
 template <int I, int N, typename F>

@@ -103,5 +103,52 @@ def test_large_conv_parity(cuda, mode):
         assert rec["wgrad"] < 2e-5, rec
 
 
+def _persist_child():
+    """1x1 convs through the 256 x 256 LDS-DMA path: digests of every output (forward, forward with fused
+    BatchNorm statistics, dgrad, accumulate-dgrad) for the parent to compare between DCFP_IGEMM_PERSIST=0/1."""
+    import hashlib
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dcfp_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    out = {}
+    # interior tiles with several tiles per CU; ragged M / K / pixel tail; one image, more tiles than CUs
+    for (N, Cin, H, W, Cout) in [(4, 256, 128, 256, 1024), (2, 264, 100, 132, 320), (1, 512, 96, 256, 2048)]:
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)).to(dev)
+        d = ops._desc(x.shape, w.shape, 1, 0, 1)
+        assert ops.conv_kernel_name(d, _lib.CONV_FWD).startswith("igemm2_dma_kernel<1"), ops.conv_kernel_name(d, _lib.CONV_FWD)
+        y = ops.conv2d_fwd(x, w, None, 1, 0, 1)
+        y2, stats = ops.conv2d_fwd(x, w, None, 1, 0, 1, want_stats=True)
+        dy = torch.randn(y.shape, generator=g).to(dev)
+        dx = ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, 0, 1)
+        seed = torch.randn(x.shape, generator=g).to(dev)
+        ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, 0, 1, out=seed, accumulate=True)
+        torch.cuda.synchronize()
+        items = [y, y2, dx, seed] + ([stats[0], stats[1]] if stats is not None else [])
+        out[f"{N}x{Cin}x{H}x{W}->{Cout}"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in items]
+    print("PERSIST_RESULT " + json.dumps(out))
+
+
+def test_persistent_1x1_kernel_bit_identical_to_one_tile_kernel(cuda):
+    """conv_igemm2p.hip (persistent workgroups, cross-tile prefetch) against igemm2_dma_kernel<1> (one tile per
+    workgroup): same tile order and arithmetic, so every output bit must agree."""
+    res = []
+    for v in ("0", "1"):
+        env = dict(os.environ, DCFP_IGEMM_PERSIST=v, DCFP_CONV_MATH="f32")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--persist-child"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("PERSIST_RESULT ")][-1]
+        res.append(json.loads(line[len("PERSIST_RESULT "):]))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 3
+    for k in res[0]:
+        assert res[0][k] == res[1][k], k
+    assert any(len(v) == 6 for v in res[0].values())        # the fused-statistics epilogue was exercised
+
+
 if __name__ == "__main__" and "--child" in sys.argv:
     _child()
+if __name__ == "__main__" and "--persist-child" in sys.argv:
+    _persist_child()
