@@ -132,7 +132,7 @@ def roofline_from_profile(recs, images_per_step, step_s):
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += work; a[1] += ms; a[2] += 1
             bn_bytes += work; bn_ms += ms
-    convs = {k: v for k, v in agg.items() if "kernel<" in k}
+    convs = {k: v for k, v in agg.items() if "kernel" in k}
     dom = max(convs, key=lambda k: convs[k][1])
     w, ms, cnt = convs[dom]
     # HBM-side bytes per launch from the committed PMC profile (cannot be collected inside this
@@ -159,7 +159,7 @@ def roofline_from_profile(recs, images_per_step, step_s):
     others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1], "launches": v[2]}
               for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])}
     hbm = {k: {"GB/s": v[0] / (v[1] * 1e-3) / 1e9, "ms_per_step": v[1], "launches": v[2]}
-           for k, v in agg.items() if "kernel<" not in k}
+           for k, v in agg.items() if "kernel" not in k}
     extra = {"conv_ms_per_step": conv_ms, "conv_TFLOP/s_over_all_convs": conv_flops / (conv_ms * 1e-3) / 1e12,
              "bn_ms_per_step": bn_ms, "bn_GB/s": bn_bytes / (bn_ms * 1e-3) / 1e9 if bn_ms else None,
              "step_conv_roofline_frac": conv_flops / step_s / PEAK_F32_MFMA,

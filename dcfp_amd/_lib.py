@@ -39,6 +39,12 @@ class BnRunning(C.Structure):
                 ("momentum", C.c_float), ("pad_", C.c_int32)]
 
 
+class WpEntry(C.Structure):
+    """DcfpWpEntry: one weight tensor -> permuted copy of the multi-tensor refresh."""
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("first_block", C.c_int64), ("n_blocks", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("T", "Ck", "CkP", "M", "Mpad", "sAm", "sAc", "pad_")]
+
+
 SGD_CHUNK = 16384
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 E_BADDESC, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3   # DCFP_E_* of include/dcfp_hip.h
@@ -51,6 +57,8 @@ _R = C.POINTER(BnRunning)
 SIGNATURES = {
     "dcfp_abi_version": (_I, []),
     "dcfp_conv2d_workspace_bytes": (_Z, [_D, _I]),
+    "dcfp_conv2d_wp_layout": (_I, [_D, _I, C.POINTER(WpEntry)]),
+    "dcfp_conv2d_permute_weights_multi_f32": (_I, [_P, _I, _L, _P]),
     "dcfp_conv2d_kernel_name": (_I, [_D, _I, C.c_char_p, _I]),
     "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P, _Z, _I, _P]),
     "dcfp_conv2d_fwd_fused_f32_nchw": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P]),

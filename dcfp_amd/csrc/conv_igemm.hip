@@ -51,6 +51,9 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0);
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
+bool dcfp_igemm2_persist();
+void dcfp_igemm2_wp_layout(int T, int M, int Ck, long long px, int sd, int sAm, int sAc, DcfpWpEntry* e);
+int dcfp_igemm2_permute_multi(const DcfpWpEntry* table, int n, long long total_blocks, hipStream_t stream);
 
 
 // implemented in conv_igemm3.hip — EXPERIMENTAL opt-in (DCFP_CONV_MATH=bf16x3): 3-way bf16 split
@@ -101,9 +104,11 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     const int HiWi = pass == DCFP_CONV_FWD ? d->H * d->W : d->Hout * d->Wout;
     const int Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
     if (dcfp_igemm2_dma_shape(d->KH * d->KW, M, Ck, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd, d->pad, HiWi,
-                              pass == DCFP_CONV_FWD ? d->Wout : d->W))
+                              pass == DCFP_CONV_FWD ? d->Wout : d->W)) {
+        if (d->KH == 1 && dcfp_igemm2_persist()) return snprintf(buf, buf_len, "igemm2_dma1p_kernel");   // <ACC>
         return snprintf(buf, buf_len, "igemm2_dma_kernel<%d,%s>", d->KH * d->KW,
                         (d->KH == 3 && ((d->pad | d->dil) & 3) != 0) ? "true" : "false");   // <TAPS, MIXED>
+    }
     return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW, dcfp_igemm2_cfg_args(M, px, sd));
 }
 
@@ -192,4 +197,32 @@ extern "C" int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float
                            (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,
                            d->Hout, d->Wout, d->stride, 1, -d->pad, d->dil, 0, workspace, workspace_bytes,
                            dcfp_s(stream), scale, shift, residual, relu ? 1 : 0, nullptr, wp_valid);
+}
+
+// Wp layout of (descriptor, pass) for a caller that refreshes the permuted copies of many convs in one
+// launch after an optimizer step (dcfp_conv2d_permute_weights_multi_f32) and then passes wp_valid = 1.
+extern "C" int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntry* e) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!e || (pass != DCFP_CONV_FWD && pass != DCFP_CONV_DGRAD)) return DCFP_E_BADDESC;
+    const int T = d->KH * d->KW;
+    if (pass == DCFP_CONV_FWD) {
+        const long long px = (long long)d->N * d->Hout * d->Wout;
+        if (igemm3_ok(d->Cout, px, d->stride, 1)) return DCFP_E_UNSUPPORTED;     // bf16x3 keeps its own split copy
+        dcfp_igemm2_wp_layout(T, d->Cout, d->Cin, px, 1, d->Cin * T, T, e);
+    } else {
+        const long long px = (long long)d->N * d->H * d->W;
+        if (igemm3_ok(d->Cin, px, 1, d->stride)) return DCFP_E_UNSUPPORTED;
+        dcfp_igemm2_wp_layout(T, d->Cin, d->Cout, px, d->stride, T, d->Cin * T, e);
+    }
+    const long long total = (long long)e->T * e->CkP * e->Mpad;
+    e->n_blocks = (total + DCFP_WP_BLOCK_ELEMS - 1) / DCFP_WP_BLOCK_ELEMS;
+    return DCFP_OK;
+}
+
+extern "C" int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, int n, int64_t total_blocks,
+                                                     dcfp_stream_t stream) {
+    if (n == 0 || total_blocks == 0) return DCFP_OK;
+    if (!table || n < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return DCFP_E_BADDESC;
+    return dcfp_igemm2_permute_multi(table, n, total_blocks, dcfp_s(stream));
 }

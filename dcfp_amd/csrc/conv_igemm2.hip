@@ -35,6 +35,34 @@ permute_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int 
     }
 }
 
+// The same permutation for MANY weight tensors in one launch (all convs of a model, forward and dgrad
+// layouts, once per optimizer step): block -> entry by binary search over first_block, 2048 elements per block.
+constexpr int kWpBlockElems = DCFP_WP_BLOCK_ELEMS;
+__global__ void __launch_bounds__(256)
+permute_weights_multi_kernel(const DcfpWpEntry* __restrict__ table, int n) {
+    const long long blk = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const DcfpWpEntry e = table[lo];
+    const long long total = (long long)e.T * e.CkP * e.Mpad;
+    const long long base = (blk - e.first_block) * kWpBlockElems;
+#pragma unroll
+    for (int u = 0; u < kWpBlockElems / 256; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i >= total) return;
+        const int m = (int)(i % e.Mpad);
+        const long long r = i / e.Mpad;
+        const int c = (int)(r % e.CkP);
+        const int t = (int)(r / e.CkP);
+        float v = 0.f;
+        if (m < e.M && c < e.Ck) v = e.w[(long long)m * e.sAm + (long long)c * e.sAc + t];
+        e.wp[i] = v;
+    }
+}
+
 // value of lane (l ^ MASK) within each 32-lane half (ds_swizzle bit-mask mode: and 0x1f, xor MASK)
 __device__ __forceinline__ float half_xor(float v, int mask) {
     switch (mask) {
@@ -762,6 +790,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // implemented in conv_igemm2p.hip: the persistent 1x1 LDS-DMA kernel
 int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream);
+bool dcfp_igemm2_persist();
 
 // ---- entry points used by conv_igemm.hip's C-ABI functions
 size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
@@ -789,6 +818,24 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
         case 4: return "4,4,2,2,0";
         default: return "2,4,2,2,1";
     }
+}
+
+// Layout of the Wp copy dcfp_igemm2_run would build for this problem (everything but the pointers)
+void dcfp_igemm2_wp_layout(int T, int M, int Ck, long long px, int sd, int sAm, int sAc, DcfpWpEntry* e) {
+    const TileCfg c = pick_cfg(M, px, sd);
+    e->T = T; e->Ck = Ck; e->CkP = round_up(Ck, ck_pad()); e->M = M; e->Mpad = round_up(M, c.bm);
+    e->sAm = sAm; e->sAc = sAc;
+}
+
+int dcfp_igemm2_permute_multi(const DcfpWpEntry* table, int n, long long total_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(permute_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, table, n);
+    DCFP_RETURN_LAUNCH();
+}
+
+// DCFP_IGEMM_PERSIST=0: 1x1 convs on the one-tile-per-workgroup kernel instead of conv_igemm2p.hip
+bool dcfp_igemm2_persist() {
+    static const bool persist = [] { const char* e = getenv("DCFP_IGEMM_PERSIST"); return !e || atoi(e) != 0; }();
+    return persist;
 }
 
 // shapes the LDS-DMA kernel takes (also used for dcfp_conv2d_kernel_name)
@@ -851,8 +898,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
             DCFP_RETURN_LAUNCH();
         };
         if (T == 1) {
-            static const bool persist = [] { const char* e = getenv("DCFP_IGEMM_PERSIST"); return !e || atoi(e) != 0; }();   // =0: one tile per workgroup
-            if (persist) return dcfp_igemm2p_launch(p, stream);
+            if (dcfp_igemm2_persist()) return dcfp_igemm2p_launch(p, stream);
             return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
         }
         if (((off0 | offstep) & 3) == 0)

@@ -31,6 +31,19 @@ def build_criterion(loss_type, dataset, loss_para):
     return cls(dataset=dataset, **loss_para)
 
 
+def class_weighted_ce(logits, target, class_weights, size, align_corner, ignore_index, pixel_keep=None):
+    """nn.CrossEntropyLoss(weight=w, ignore_index, 'mean') of the upsampled logits (criterion.py:54-60):
+    sum_i w[y_i] * nll_i / sum_i w[y_i] over the valid (and kept) pixels, through the fused weighted-CE
+    kernels with the per-pixel weight w[y_i]."""
+    w = class_weights.to(device=logits.device, dtype=torch.float32)
+    valid = target != ignore_index
+    if pixel_keep is not None:
+        valid = valid & (pixel_keep != 0)
+    pix_w = w[target.clamp(min=0, max=w.numel() - 1)] * valid
+    out = ops.upsample_weighted_ce(logits, target, pix_w, size, align_corner, ignore_index)   # [N, 2] = (sum w*ce, sum w)
+    return out[:, 0].sum() / out[:, 1].sum()
+
+
 class CombinedCriterion(nn.Module):
     """criterion.py:30-45: sum of the 'loss' entries of several criteria."""
 
@@ -65,10 +78,14 @@ class CriterionDSN(nn.Module):
         super().__init__()
         self.ignore_index = dataset.ignore_label
         self.ds_weight = ds_weight
+        # criterion.py:54-60: nn.CrossEntropyLoss(weight=dataset.class_weights) when balance_weight
+        self.class_weights = None
         if balance_weight:
-            raise NotImplementedError("class-weighted CE (balance_weight) is not on the DCFP configs")
+            self.class_weights = torch.as_tensor(dataset.class_weights, dtype=torch.float32)
 
     def _ce(self, logits, target, size, align_corner):
+        if self.class_weights is not None:
+            return class_weighted_ce(logits, target, self.class_weights, size, align_corner, self.ignore_index)
         return ops.upsample_cross_entropy(logits, target, size, align_corner, self.ignore_index)
 
     def forward_lowres(self, preds, target, size, align_corner):

@@ -21,8 +21,8 @@ from .._lib import check
 class OhemCrossEntropy2d(nn.Module):
     def __init__(self, weight=None, ignore_label=255, thresh=0.7, min_kept=100000, factor=8):
         super().__init__()
-        if weight is not None:
-            raise NotImplementedError("class-weighted OHEM is not on the DCFP configs")
+        # class weights of the final CrossEntropyLoss (ohem.py:18); the threshold search does not use them
+        self.class_weights = None if weight is None else torch.as_tensor(weight, dtype=torch.float32)
         self.ignore_label = ignore_label
         self.thresh = float(thresh)
         self.min_kept = int(min_kept)
@@ -66,6 +66,9 @@ class OhemCrossEntropy2d(nn.Module):
         check(_lib.lib().dcfp_ohem_keep_mask_u8(   # ohem.py:69: kept_flag = pred <= threshold
             C.c_void_p(gtp.data_ptr()), C.c_void_p(thr.data_ptr()), gtp.numel(), C.c_void_p(keep.data_ptr()),
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ohem_keep_mask")
+        if self.class_weights is not None:
+            from .criterion import class_weighted_ce
+            return class_weighted_ce(logits, target, self.class_weights, size, align_corner, self.ignore_label, keep)
         return ops.upsample_cross_entropy(logits, target, size, align_corner, self.ignore_label,
                                           pixel_keep=keep)
 
@@ -80,16 +83,20 @@ class CriterionOhemDSN(nn.Module):
     def __init__(self, dataset=None, ds_weight=0.4, balance_weight=False, ohem_thres=0.7,
                  ohem_keep=100000, **kwargs):
         super().__init__()
-        if balance_weight:
-            raise NotImplementedError("class-weighted OHEM is not on the DCFP configs")
         self.ignore_index = dataset.ignore_label
         self.ds_weight = ds_weight
-        self.criterion1 = OhemCrossEntropy2d(None, self.ignore_index, ohem_thres, ohem_keep)
+        weight = dataset.class_weights if balance_weight else None        # ohem.py:105-108
+        self.class_weights = None if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+        self.criterion1 = OhemCrossEntropy2d(weight, self.ignore_index, ohem_thres, ohem_keep)
 
     def forward_lowres(self, preds, target, size, align_corner):
         loss = self.criterion1.forward_lowres(preds[0], target, size, align_corner)
         if len(preds) >= 2:
-            loss2 = ops.upsample_cross_entropy(preds[1], target, size, align_corner, self.ignore_index)
+            if self.class_weights is not None:
+                from .criterion import class_weighted_ce
+                loss2 = class_weighted_ce(preds[1], target, self.class_weights, size, align_corner, self.ignore_index)
+            else:
+                loss2 = ops.upsample_cross_entropy(preds[1], target, size, align_corner, self.ignore_index)
             loss = loss + loss2 * self.ds_weight
         return {"loss": loss}
 

@@ -6,6 +6,7 @@ tensors — there is deliberately no CPU / eager fallback.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -118,11 +119,17 @@ FUSE_BN_STATS = os.environ.get("DCFP_FUSED_BN_STATS", "1") not in ("0",)
 BN_RELU_BITMASK = os.environ.get("DCFP_BN_RELU_BITMASK", "1") not in ("0",)
 
 
+_WP_OWNERS = weakref.WeakSet()     # weight tensors that carry permuted copies (w._dcfp_wp)
+_WP_TABLE = {"version": 0, "built": -1, "dev": None, "n": 0, "blocks": 0, "entries": []}
+
+
 def _wp_buffer(w, which, d, nbytes):
     """Persistent buffer for the permuted weight copy Wp of (weight tensor, pass, shape) and whether the
-    library may skip rebuilding it: weights change once per optimizer step, so forward and dgrad each
-    permute at most once per step instead of on every call (`wp_valid` of include/dcfp_hip.h).  Validity =
-    same storage, same torch version counter and same WEIGHT_EPOCH (raw-pointer writes by FusedSGD)."""
+    library may skip rebuilding it (`wp_valid` of include/dcfp_hip.h).  Validity = same storage, same torch
+    version counter and same WEIGHT_EPOCH (raw-pointer writes by FusedSGD).  In training every weight changes
+    once per step: FusedSGD.step() then calls refresh_wp(), ONE multi-tensor launch that rebuilds every
+    registered copy (forward and dgrad layouts of all convs) and re-validates them, instead of a permute
+    launch inside each of the 233 conv calls of a step."""
     key = (which, d.N, d.H, d.W, d.stride, d.pad, d.dil)
     tag = (w.data_ptr(), w._version, WEIGHT_EPOCH[0], torch.cuda.current_stream().cuda_stream)
     cache = getattr(w, "_dcfp_wp", None)
@@ -130,19 +137,63 @@ def _wp_buffer(w, which, d, nbytes):
         cache = {}
         try:
             w._dcfp_wp = cache
+            _WP_OWNERS.add(w)
         except Exception:        # not an attribute-bearing tensor: no caching
             return _workspace("conv", nbytes, w.device), 0
     ent = cache.get(key)
     if ent is not None and ent[1].numel() >= nbytes:
         if ent[0] == tag:
             return ent[1], 1
-        cache[key] = (tag, ent[1])
+        cache[key] = (tag, ent[1], ent[2])
         return ent[1], 0
     if len(cache) > 8:           # shapes keep changing (multi-scale evaluation): do not hoard buffers
         cache.clear()
     buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=w.device)
-    cache[key] = (tag, buf)
+    cache[key] = (tag, buf, ConvDesc(*[getattr(d, f[0]) for f in ConvDesc._fields_]))
+    _WP_TABLE["version"] += 1
     return buf, 0
+
+
+def refresh_wp():
+    """After an in-place weight update: rebuild every registered Wp copy with one launch and mark them valid
+    for the current WEIGHT_EPOCH.  The device table of (weights, copy, layout) records is rebuilt only when
+    the set of registered copies changed (first steps of a run)."""
+    T = _WP_TABLE
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    if T["built"] != T["version"]:
+        ents, recs, first = [], [], 0
+        for w in list(_WP_OWNERS):
+            if not w.is_cuda or not w.is_contiguous():
+                continue
+            for key, (tag, buf, desc) in list(w._dcfp_wp.items()):
+                e = _lib.WpEntry()
+                if L.dcfp_conv2d_wp_layout(C.byref(desc), key[0], C.byref(e)) != 0:
+                    continue
+                e.w, e.wp, e.first_block = w.data_ptr(), buf.data_ptr(), first
+                first += e.n_blocks
+                recs.append(e); ents.append((weakref.ref(w), key))
+        T["entries"], T["n"], T["blocks"] = ents, len(recs), first
+        if recs:
+            arr = (_lib.WpEntry * len(recs))(*recs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            T["dev"] = host.to(torch.device("cuda", torch.cuda.current_device()))
+        T["built"] = T["version"]
+        T["ptrs"] = [e.w for e in recs]
+    if not T["n"]:
+        return
+    live = []
+    for (wr, key), ptr in zip(T["entries"], T["ptrs"]):
+        w = wr()
+        if w is None or w.data_ptr() != ptr or key not in w._dcfp_wp:     # a weight went away / moved: rebuild next time
+            T["version"] += 1
+            return
+        live.append((w, key))
+    check(L.dcfp_conv2d_permute_weights_multi_f32(C.c_void_p(T["dev"].data_ptr()), T["n"], T["blocks"],
+                                                  C.c_void_p(stream)), "permute_weights_multi")
+    for w, key in live:
+        _, buf, desc = w._dcfp_wp[key]
+        w._dcfp_wp[key] = ((w.data_ptr(), w._version, WEIGHT_EPOCH[0], stream), buf, desc)
 
 
 def _bn_run(running_mean, running_var, momentum, nbt):

@@ -127,6 +127,7 @@ class FusedSGD(torch.optim.Optimizer):
                                           float(group["momentum"]), 0, stream), "sgd_momentum")
         from . import ops
         ops.WEIGHT_EPOCH[0] += 1
+        ops.refresh_wp()          # one launch: the permuted copies the conv kernels read, for the new weights
         return loss
 
 

@@ -65,6 +65,25 @@ enum { DCFP_CONV_FWD = 0, DCFP_CONV_DGRAD = 1, DCFP_CONV_WGRAD = 2 };
  * buffer per conv and pass and permutes at most once per step). */
 size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass);
 
+/* One launch for the Wp copies of MANY convs (a model's forward and dgrad layouts after an optimizer
+ * step: optimizer.py:24-25 changes every weight once per iteration).  dcfp_conv2d_wp_layout fills the
+ * layout fields and n_blocks of an entry for (descriptor, pass) (DCFP_E_UNSUPPORTED where the pass keeps
+ * another kind of copy, e.g. DCFP_CONV_MATH=bf16x3); the caller sets w (reference-layout weights), wp
+ * (its persistent buffer of dcfp_conv2d_workspace_bytes) and first_block = prefix sum of n_blocks, uploads
+ * the table once, and after every weight update launches dcfp_conv2d_permute_weights_multi_f32 and passes
+ * wp_valid = 1 to the conv calls. */
+#define DCFP_WP_BLOCK_ELEMS 2048
+typedef struct DcfpWpEntry {
+    const float* w;
+    float* wp;
+    int64_t first_block;
+    int64_t n_blocks;
+    int32_t T, Ck, CkP, M, Mpad, sAm, sAc, pad_;
+} DcfpWpEntry;
+int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntry* entry);
+int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, int n_entries, int64_t total_blocks,
+                                          dcfp_stream_t stream);
+
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
  * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the
  * string rocprofv3 shows (demangled) for the launch; used by bench.py to label rooflines.

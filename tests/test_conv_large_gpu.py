@@ -86,7 +86,7 @@ def test_large_conv_parity(cuda, mode):
     res = json.loads(line[len("BF16X3_RESULT "):])
     assert len(res) == len(CASES)
     fwd_kernel, wgrad_kernel = ("igemm3_kernel", "wgrad3_kernel") if mode == "bf16x3" else \
-        ("igemm2_", "wgrad2_kernel")     # igemm2_kernel<...> or the LDS-DMA igemm2_dma_kernel<1>
+        ("igemm2_", "wgrad2_kernel")     # igemm2_kernel<...>, igemm2_dma_kernel<9,..> or the persistent igemm2_dma1p_kernel
     assert sum(rec["kernels"][2].startswith(wgrad_kernel) for rec in res) >= 2, res
     if mode == "f32":   # the +-1 tap case goes through the LDS-DMA wgrad with shifted 16-byte copies
         assert res[3]["kernels"][2] == "wgrad_dma_kernel<9,true>", res[3]["kernels"]
@@ -118,7 +118,8 @@ def _persist_child():
         x = torch.randn(N, Cin, H, W, generator=g).to(dev)
         w = (torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)).to(dev)
         d = ops._desc(x.shape, w.shape, 1, 0, 1)
-        assert ops.conv_kernel_name(d, _lib.CONV_FWD).startswith("igemm2_dma_kernel<1"), ops.conv_kernel_name(d, _lib.CONV_FWD)
+        want = "igemm2_dma1p_kernel" if os.environ.get("DCFP_IGEMM_PERSIST") != "0" else "igemm2_dma_kernel<1"
+        assert ops.conv_kernel_name(d, _lib.CONV_FWD).startswith(want), ops.conv_kernel_name(d, _lib.CONV_FWD)
         y = ops.conv2d_fwd(x, w, None, 1, 0, 1)
         y2, stats = ops.conv2d_fwd(x, w, None, 1, 0, 1, want_stats=True)
         dy = torch.randn(y.shape, generator=g).to(dev)

@@ -186,8 +186,8 @@ def test_config3_conv_power_of_two_homogeneity(cuda, shape):
 # stride-2 dgrad) against fp64 on a channel slice; expected kernel family per pass as a routing check
 SLICE_SHAPES = [
     ((4, 256, 128, 256, 256, 3, 1, 2, 2), ("igemm2_dma_kernel<9,true>", "wgrad_dma_kernel<9,true>")),     # layer3 conv2
-    ((4, 256, 128, 256, 1024, 1, 1, 0, 1), ("igemm2_dma_kernel<1,false>", "wgrad_dma_kernel<1,false>")),  # layer3 conv3
-    ((4, 1024, 128, 256, 256, 1, 1, 0, 1), ("igemm2_dma_kernel<1,false>", "wgrad_dma_kernel<1,false>")),  # layer3 conv1
+    ((4, 256, 128, 256, 1024, 1, 1, 0, 1), ("igemm2_dma1p_kernel", "wgrad_dma_kernel<1,false>")),  # layer3 conv3
+    ((4, 1024, 128, 256, 256, 1, 1, 0, 1), ("igemm2_dma1p_kernel", "wgrad_dma_kernel<1,false>")),  # layer3 conv1
     ((4, 2048, 128, 256, 256, 3, 1, 12, 12), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # ASPP
     ((4, 1024, 128, 256, 512, 3, 1, 1, 1), ("igemm2_dma_kernel<9,true>", "wgrad_dma_kernel<9,true>")),    # conv_deepsup.0
     ((4, 64, 512, 1024, 128, 3, 1, 1, 1), (None, None)),                                                  # stem

@@ -325,6 +325,44 @@ def test_ohem_fullsize_vs_oracle(cuda):
         assert torch.isfinite(zg.grad).all()
 
 
+@pytest.mark.parametrize("loss_type", ["ce", "ohem"])
+def test_class_weighted_criterions(cuda, loss_type):
+    """balance_weight=True: nn.CrossEntropyLoss(weight=dataset.class_weights, ignore_index) in CriterionDSN
+    (loss/criterion.py:54-60) and in CriterionOhemDSN (loss/ohem.py:105-110), both heads, against the same
+    torch losses on the materialised upsampled logits (OHEM relabelling by the oracle)."""
+    import numpy as np
+    from oracle import ohem as oohem
+    from dcfp_amd.loss.criterion import build_criterions
+    N, Cc, h, w, H, W = 2, 7, 9, 13, 65, 97
+
+    class DS:
+        ignore_label = 255; num_classes = Cc
+        class_weights = torch.tensor([0.8, 1.3, 0.5, 2.0, 1.0, 0.25, 1.7])
+    g = torch.Generator().manual_seed(9)
+    z0 = (torch.randn(N, Cc, h, w, generator=g) * 2).requires_grad_(True)
+    z1 = torch.randn(N, Cc, h, w, generator=g).requires_grad_(True)
+    lab = torch.randint(0, Cc, (N, H, W), generator=g)
+    lab[torch.rand(N, H, W, generator=g) < 0.1] = 255
+    para = {"ds_weight": 0.4, "balance_weight": True}
+    if loss_type == "ohem":
+        para.update(ohem_thres=0.3, ohem_keep=64 * 40)
+    crit = build_criterions(loss_type, DS(), para)
+    up0 = F.interpolate(z0.double(), size=(H, W), mode="bilinear", align_corners=True)
+    up1 = F.interpolate(z1.double(), size=(H, W), mode="bilinear", align_corners=True)
+    t0 = lab
+    if loss_type == "ohem":
+        nt, _ = oohem.new_target(torch.softmax(up0.detach().float(), 1).numpy(), lab.numpy(), 255, 0.3, 64 * 40)
+        t0 = torch.from_numpy(nt).long()
+    wd = DS.class_weights.double()
+    ref = F.cross_entropy(up0, t0, weight=wd, ignore_index=255) + 0.4 * F.cross_entropy(up1, lab, weight=wd, ignore_index=255)
+    ref.backward()
+    g0 = z0.detach().to(cuda).requires_grad_(True); g1 = z1.detach().to(cuda).requires_grad_(True)
+    loss = crit.forward_lowres([g0, g1], lab.to(cuda), (H, W), True)["loss"]
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    assert rel_err(g0.grad, z0.grad) < 1e-4 and rel_err(g1.grad, z1.grad) < 1e-4
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_gsrl_loss_vs_reference_golden(cuda, tag):
     """CriterionGsrlDSN through the fused HIP kernels vs the reference's output (golden)."""
