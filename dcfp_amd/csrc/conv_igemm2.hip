@@ -105,7 +105,13 @@ igemm2_kernel(const Igemm2Params p) {
     const int mt = local >> 3;
     if (nt >= p.tiles_n_total) return;
     const int img = nt / p.tiles_per_img;
-    const int p0 = (nt - img * p.tiles_per_img) * BN;
+    const int ti_img = nt - img * p.tiles_per_img;
+    // Strided data gradient (SD): a pixel tile holds output pixels of ONE phase (h % sd, w % sd) - BN consecutive
+    // positions of that phase's coarse grid - so only the taps that can reach the phase are run: no MFMA
+    // work on structural zeros (with mixed-phase tiles 3 of 4 products of a stride-2 dgrad were zero).
+    const int phase = SD ? (p.zfold ? p.zfold - 1 : ti_img / p.tiles_per_phase) : 0;
+    const int ph_h = SD ? phase / p.sd : 0, ph_w = SD ? phase - ph_h * p.sd : 0;
+    const int p0 = (SD && !p.zfold ? ti_img - phase * p.tiles_per_phase : ti_img) * BN;
     const int m0 = mt * BM;
 
     const int tid = threadIdx.x;
@@ -125,18 +131,40 @@ igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int pp = p0 + 4 * tx + e;
-        pv[e] = pp < p.P;
-        const int oh = pp / p.Wo;
-        const int ow = pp - oh * p.Wo;
-        bh[e] = oh * p.sn;
-        bw[e] = ow * p.sn;
+        if constexpr (SD) {
+            const int a = pp / p.Wc, b = pp - a * p.Wc;
+            const int oh = a * p.sd + ph_h, ow = b * p.sd + ph_w;
+            pv[e] = a < p.Hc && oh < p.Ho && ow < p.Wo;
+            bh[e] = oh * p.sn;
+            bw[e] = ow * p.sn;
+        } else {
+            pv[e] = pp < p.P;
+            const int oh = pp / p.Wo;
+            const int ow = pp - oh * p.Wo;
+            bh[e] = oh * p.sn;
+            bw[e] = ow * p.sn;
+        }
     }
     const int HiWi = p.Hi * p.Wi;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in + (long long)img * p.in_nstride), 0, p.Ck * HiWi * 4, 0x00020000);
 
     const int ksteps_per_tap = p.CkP / BK;
-    const int nk = TAPS * ksteps_per_tap;
+    // SD: the taps whose source row / column is a multiple of sd for this phase, packed 4 bits each
+    unsigned long long tap_list = 0;
+    int ntaps = TAPS;
+    if constexpr (SD) {
+        ntaps = 0;
+        for (int t = 0; t < TAPS; ++t) {
+            const int kh = (TAPS == 9) ? t / 3 : 0, kw = (TAPS == 9) ? t - kh * 3 : 0;
+            const int sh = ph_h + p.off0 + kh * p.offstep, sw = ph_w + p.off0 + kw * p.offstep;
+            if (sh % p.sd == 0 && sw % p.sd == 0) {
+                tap_list |= (unsigned long long)t << (4 * ntaps);
+                ++ntaps;
+            }
+        }
+    }
+    const int nk = ntaps * ksteps_per_tap;
 
     unsigned boff[4];            // per-pixel byte offsets of the current tap (kOob when padded)
     bool bvec = false;           // the 4 pixels are one contiguous in-image run (or all padding)
@@ -180,8 +208,9 @@ igemm2_kernel(const Igemm2Params p) {
         const int c0 = cb * BK;
         if (PART == 0 && (TAPS > 1 || kt == 0)) set_tap(t);
 #else
-        const int t = kt / ksteps_per_tap;
-        const int c0 = (kt - t * ksteps_per_tap) * BK;
+        const int ti_ = kt / ksteps_per_tap;
+        const int c0 = (kt - ti_ * ksteps_per_tap) * BK;
+        const int t = SD ? (int)((tap_list >> (4 * ti_)) & 15ull) : ti_;
         if (PART == 0 && c0 == 0) set_tap(t);
 #endif
         static_for<0, APASS>([&](auto j_) {
@@ -239,9 +268,11 @@ igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    static_for<0, NPART>([&](auto part_) { load_part(0, part_); });
-    store_a(0);
-    store_b(0);
+    if (nk > 0) {     // (SD: a phase no tap reaches is all zeros - 1x1 stride-2 dgrads are 3/4 of that)
+        static_for<0, NPART>([&](auto part_) { load_part(0, part_); });
+        store_a(0);
+        store_b(0);
+    }
     __syncthreads();
 
     const int a_off = wm * (TM * 32) + TM * l31;
@@ -292,7 +323,7 @@ igemm2_kernel(const Igemm2Params p) {
         // Interior tile of a plain training conv (block-uniform test): 16-byte stores through a
         // buffer descriptor whose base is block-uniform, row offsets scalar (soffset) and the
         // lane's column a single VGPR - no per-row predicates or 64-bit address arithmetic.
-        if (m0 + BM <= p.M && p0 + BN <= p.P && p.vec_store && !p.bias && !p.scale && !p.relu) {
+        if (!SD && m0 + BM <= p.M && p0 + BN <= p.P && p.vec_store && !p.bias && !p.scale && !p.relu) {
             constexpr unsigned kMaxRec = 0x7ffffffcu;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 o_img + (long long)m0 * p.P + p0, 0, kMaxRec, 0x00020000);
@@ -377,6 +408,94 @@ igemm2_kernel(const Igemm2Params p) {
     // pointers from being hoisted above the K loop
     int pix = p0 + wn * (TN * 32) + TN * l31;
     asm volatile("" : "+v"(pix));
+    if constexpr (SD) {
+        // the lane's TN coarse positions -> fine offsets (h * Wo + w), -1 where the phase has no such pixel;
+        // 4-byte stores 2 floats apart (the other phases' tiles fill the gaps)
+        int foff[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pp = pix + j;
+            const int a = pp / p.Wc, b = pp - a * p.Wc;
+            const int oh = a * p.sd + ph_h, ow = b * p.sd + ph_w;
+            foff[j] = (a < p.Hc && oh < p.Ho && ow < p.Wo) ? oh * p.Wo + ow : -1;
+        }
+        if constexpr (!ACC && TN == 4) {
+            // 1x1 stride-2: this phase's tiles are the only ones; a lane's 4 coarse pixels become the 8
+            // consecutive fine pixels [v0 0 v1 0 v2 0 v3 0] of row 2a (+ph_h) and 8 zeros of the other row phase:
+            // four 16-byte stores instead of 32 scattered 4-byte ones from four different tiles
+            if (p.zfold && p.sd == 2 && (p.Wo & 1) == 0 && (p.Wc & 3) == 0 && p.vec_store) {
+                const int a = pix / p.Wc, b = pix - a * p.Wc;
+                if (a < p.Hc) {
+                    const int oh = 2 * a + ph_h, oz = 2 * a + (1 - ph_h);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            const int m = m0 + wm * (TM * 32) + TM * row + i;
+                            if (m >= p.M) continue;
+                            float* dst = o_img + (long long)m * p.P + 2 * b;
+                            const float v0 = acc[i][0][r], v1 = acc[i][1][r], v2 = acc[i][2][r], v3 = acc[i][3][r];
+                            const float4 lo = ph_w ? make_float4(0.f, v0, 0.f, v1) : make_float4(v0, 0.f, v1, 0.f);
+                            const float4 hi = ph_w ? make_float4(0.f, v2, 0.f, v3) : make_float4(v2, 0.f, v3, 0.f);
+                            if (oh < p.Ho) {
+                                *reinterpret_cast<float4*>(dst + (long long)oh * p.Wo) = lo;
+                                *reinterpret_cast<float4*>(dst + (long long)oh * p.Wo + 4) = hi;
+                            }
+                            if (oz < p.Ho) {
+                                *reinterpret_cast<float4*>(dst + (long long)oz * p.Wo) = make_float4(0.f, 0.f, 0.f, 0.f);
+                                *reinterpret_cast<float4*>(dst + (long long)oz * p.Wo + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        }
+                    }
+                }
+                return;
+            }
+        }
+        if (p.zfold && !ACC) {   // generic form of the same: every phase's position of the lane's coarse pixels
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int m = m0 + wm * (TM * 32) + TM * row + i;
+                    if (m >= p.M) continue;
+                    float* dst = o_img + (long long)m * p.P;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int pp = pix + j;
+                        const int a = pp / p.Wc, b = pp - a * p.Wc;
+                        if (a >= p.Hc) continue;
+                        for (int qh = 0; qh < p.sd; ++qh)
+                            for (int qw = 0; qw < p.sd; ++qw) {
+                                const int oh = a * p.sd + qh, ow = b * p.sd + qw;
+                                if (oh < p.Ho && ow < p.Wo)
+                                    dst[oh * p.Wo + ow] = (qh == ph_h && qw == ph_w) ? acc[i][j][r] : 0.f;
+                            }
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int m = m0 + wm * (TM * 32) + TM * row + i;
+                if (m >= p.M) continue;
+                float* dst = o_img + (long long)m * p.P;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (foff[j] < 0) continue;
+                    float v = acc[i][j][r];
+                    if (ACC) v += dst[foff[j]];
+                    dst[foff[j]] = v;
+                }
+            }
+        }
+        return;
+    }
     const bool vec = (TN == 4) && p.vec_store && (pix + 3 < p.P);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -868,6 +987,17 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         p.tile2d = (fits && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
     }
     p.tiles_per_img = (p.P + c.bn - 1) / c.bn;
+    p.Hc = p.Wc = p.tiles_per_phase = p.zfold = 0;
+    if (sd > 1) {     // strided dgrad: sd*sd phases, each tiled over its own coarse grid
+        p.Hc = (Ho + sd - 1) / sd; p.Wc = (Wo + sd - 1) / sd;
+        p.tiles_per_phase = (p.Hc * p.Wc + c.bn - 1) / c.bn;
+        p.tiles_per_img = sd * sd * p.tiles_per_phase;
+        if (T == 1) {   // a 1x1 conv reaches ONE phase: only that phase gets tiles (they also write the zeros)
+            const int ph = ((-off0) % sd + sd) % sd;
+            p.zfold = ph * sd + ph + 1;
+            p.tiles_per_img = p.tiles_per_phase;
+        }
+    }
     p.tiles_n_total = p.tiles_per_img * N;
     p.tiles_m = p.Mpad / c.bm;
     p.sn = sn; p.sd = sd; p.off0 = off0; p.offstep = offstep;

@@ -38,6 +38,65 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+# lop-sided weight-gradient tiles (conv_wgrad.hip cfg 3 / 4 / 5: 256 x 128, 256 x 64, 64 x 256), 1x1 and 3x3,
+# with ragged M / N and the kernel each is expected to route to
+LOPSIDED = [
+    ((2, 128, 33, 40, 512, 1, 1, 0, 1), "wgrad2_kernel<1,4,2,2,2>"),   # layer2 conv3-like: M 512, Nn 128
+    ((2, 100, 20, 28, 300, 1, 1, 0, 1), "wgrad2_kernel<1,4,2,2,2>"),   # ragged M and Nn
+    ((2, 64, 40, 48, 256, 1, 1, 0, 1), "wgrad2_kernel<1,4,1,2,2>"),    # layer1 conv3: M 256, Nn 64
+    ((1, 47, 17, 23, 150, 1, 1, 0, 1), "wgrad2_kernel<1,4,1,2,2>"),
+    ((2, 256, 24, 36, 64, 1, 1, 0, 1), "wgrad2_kernel<1,1,4,2,2>"),    # layer1 conv1: M 64, Nn 256
+    ((2, 64, 30, 44, 64, 3, 1, 1, 1), "wgrad2_kernel<9,1,4,2,2>"),     # stem / layer1 3x3: M 64, Nn 576
+    ((1, 95, 19, 21, 40, 3, 2, 1, 1), "wgrad2_kernel<9,1,4,2,2>"),     # stride 2, ragged
+    ((2, 12, 21, 33, 200, 3, 1, 2, 2), "wgrad2_kernel<9,4,2,2,2>"),    # Nn 108
+    ((2, 5, 25, 31, 256, 3, 1, 1, 1), "wgrad2_kernel<9,4,1,2,2>"),     # Nn 45
+]
+
+
+@pytest.mark.parametrize("case,kernel", LOPSIDED)
+def test_lopsided_wgrad_tiles(cuda, case, kernel):
+    from dcfp_amd import ops, _lib
+    N, Cin, H, W, Cout, k, s, p, d = case
+    desc = ops._desc((N, Cin, H, W), (Cout, Cin, k, k), s, p, d)
+    assert ops.conv_kernel_name(desc, _lib.CONV_WGRAD) == kernel
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w64 = (torch.randn(Cout, Cin, k, k, generator=g).double()).requires_grad_(True)
+    y64 = F.conv2d(x.double(), w64, None, s, p, d)
+    dy = torch.randn(y64.shape, generator=g)
+    y64.backward(dy.double())
+    dw, db = ops.conv2d_wgrad(dy.to(cuda), x.to(cuda), tuple(w64.shape), s, p, d, need_bias=True)
+    assert rel(dw, w64.grad) < 2e-5, rel(dw, w64.grad)
+    assert rel(db, dy.double().sum((0, 2, 3))) < 1e-5
+
+
+# stride-2 data gradients: tiles hold one output phase (h % 2, w % 2) and run only the taps that reach it; a 1x1
+# conv reaches one phase, whose tiles write the zeros of the other three (vector form when W is a multiple of 8)
+STRIDED = [(2, 64, 32, 48, 96, 1, 2, 0, 1), (1, 32, 33, 50, 40, 1, 2, 0, 1), (2, 20, 16, 24, 300, 1, 2, 0, 1),
+           (2, 16, 16, 16, 24, 3, 2, 1, 1), (1, 16, 17, 19, 24, 3, 2, 1, 1), (1, 8, 20, 24, 16, 3, 2, 2, 2),
+           (1, 8, 21, 25, 16, 3, 2, 0, 1), (2, 130, 30, 34, 140, 3, 2, 1, 1), (1, 12, 18, 18, 8, 3, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", STRIDED)
+def test_strided_dgrad_phases(cuda, case):
+    from dcfp_amd import ops
+    N, Cin, H, W, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(23)
+    x64 = torch.randn(N, Cin, H, W, generator=g).double().requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    y64 = F.conv2d(x64, w.double(), None, s, p, d)
+    dy = torch.randn(y64.shape, generator=g)
+    y64.backward(dy.double())
+    dx = torch.full((N, Cin, H, W), float("nan"), device=cuda)          # every element must be written
+    ops.conv2d_dgrad(dy.to(cuda), w.to(cuda), (N, Cin, H, W), s, p, d, out=dx, accumulate=False)
+    assert torch.isfinite(dx).all()
+    assert rel(dx, x64.grad) < 1e-5, rel(dx, x64.grad)
+    seed = torch.randn(N, Cin, H, W, generator=g)
+    dxa = seed.to(cuda)
+    ops.conv2d_dgrad(dy.to(cuda), w.to(cuda), (N, Cin, H, W), s, p, d, out=dxa, accumulate=True)
+    assert rel(dxa, x64.grad + seed.double()) < 1e-5
+
+
 @pytest.mark.parametrize("case", _cases(36, 20240607))
 def test_random_conv(cuda, case):
     from dcfp_amd import ops

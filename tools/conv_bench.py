@@ -25,6 +25,12 @@ SHAPES = {
     "stem3_3x3": (4, 64, 512, 1024, 128, 3, 1, 1, 1),
     "l1c2_3x3": (4, 64, 256, 512, 64, 3, 1, 1, 1),
     "l2c2_3x3": (4, 128, 128, 256, 128, 3, 1, 1, 1),
+    "l2c2_3x3s2": (4, 128, 256, 512, 128, 3, 2, 1, 1),      # layer2.0 conv2 (stride 2)
+    "l2ds_1x1s2": (4, 256, 256, 512, 512, 1, 2, 0, 1),      # layer2.0 downsample (stride 2)
+    "l1c3_1x1": (4, 64, 256, 512, 256, 1, 1, 0, 1),
+    "l1c1_1x1": (4, 256, 256, 512, 64, 1, 1, 0, 1),
+    "l2c3_1x1": (4, 128, 128, 256, 512, 1, 1, 0, 1),
+    "l2c1_1x1": (4, 512, 128, 256, 128, 1, 1, 0, 1),
     # layer3 block after a 60 %-FLOPs prune (tools/pipeline_cfg5.sh): widths off every tile grid
     "p_l3c1_1x1": (4, 1024, 128, 256, 236, 1, 1, 0, 1),
     "p_l3c2_3x3d2": (4, 236, 128, 256, 232, 3, 1, 2, 2),
