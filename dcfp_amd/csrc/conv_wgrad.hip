@@ -635,13 +635,14 @@ Plan make_plan(const DcfpConvDesc* d) {
     const int M = d->Cout, Nn = d->Cin * d->KH * d->KW;
     // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave), and - round 2 - tiles for the lop-sided weight
     // shapes of layer1 / layer2 / the stem, which used to fall to the one-wave tile (55..81 TF):
-    // 3 = 256x128, 4 = 256x64 (tall: many output channels, <= 128 / <= 64 input columns), 5 = 64x256 (M <= 64)
+    // 3 = 256x128, 4 = 256x64 (tall: many output channels, <= 128 / <= 64 input columns): +13..15 % on the
+    // layer1 / layer2 conv3 shapes.  (A 64x256 tile for M <= 64 measured WORSE than the one-wave 64x64 tile -
+    // 65 vs 91 TF on the 64-channel 3x3 convs, 61 vs 65 TF on 256->64 1x1 - and is not used.)
     static const bool lopsided = [] { const char* e = getenv("DCFP_WGRAD_LOPSIDED"); return !e || atoi(e) != 0; }();   // =0: off
     if (M > 128 && Nn > 128) { pl.cfg = 0; pl.bm = 256; pl.bn = 256; }
     else if (M > 64 && Nn > 128) { pl.cfg = 1; pl.bm = 128; pl.bn = 256; }
     else if (lopsided && M > 128 && Nn > 64) { pl.cfg = 3; pl.bm = 256; pl.bn = 128; }
     else if (lopsided && M > 128 && Nn > 32) { pl.cfg = 4; pl.bm = 256; pl.bn = 64; }
-    else if (lopsided && M > 32 && Nn > 128) { pl.cfg = 5; pl.bm = 64; pl.bn = 256; }
     else { pl.cfg = 2; pl.bm = 64; pl.bn = 64; }
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (Nn + pl.bn - 1) / pl.bn;
@@ -749,7 +750,6 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
         case 1: return launch_cfg<TAPS, 2, 4, 2, 2>(p, blocks, stream);
         case 3: return launch_cfg<TAPS, 4, 2, 2, 2>(p, blocks, stream);
         case 4: return launch_cfg<TAPS, 4, 1, 2, 2>(p, blocks, stream);
-        case 5: return launch_cfg<TAPS, 1, 4, 2, 2>(p, blocks, stream);
         default: return launch_cfg<TAPS, 2, 2, 1, 1>(p, blocks, stream);
     }
 }
@@ -759,7 +759,7 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
-                       pl.cfg == 4 ? "4,1,2,2" : pl.cfg == 5 ? "1,4,2,2" : "2,2,1,1";
+                       pl.cfg == 4 ? "4,1,2,2" : "2,2,1,1";
     if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
     if (wgrad_dma_ok(d, pl.cfg))
         return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,%s>", d->KH * d->KW, wgrad_dma_mixed(d) ? "true" : "false");

@@ -38,16 +38,15 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-# lop-sided weight-gradient tiles (conv_wgrad.hip cfg 3 / 4 / 5: 256 x 128, 256 x 64, 64 x 256), 1x1 and 3x3,
+# lop-sided weight-gradient tiles (conv_wgrad.hip cfg 3 / 4: 256 x 128, 256 x 64), 1x1 and 3x3,
 # with ragged M / N and the kernel each is expected to route to
 LOPSIDED = [
     ((2, 128, 33, 40, 512, 1, 1, 0, 1), "wgrad2_kernel<1,4,2,2,2>"),   # layer2 conv3-like: M 512, Nn 128
     ((2, 100, 20, 28, 300, 1, 1, 0, 1), "wgrad2_kernel<1,4,2,2,2>"),   # ragged M and Nn
     ((2, 64, 40, 48, 256, 1, 1, 0, 1), "wgrad2_kernel<1,4,1,2,2>"),    # layer1 conv3: M 256, Nn 64
     ((1, 47, 17, 23, 150, 1, 1, 0, 1), "wgrad2_kernel<1,4,1,2,2>"),
-    ((2, 256, 24, 36, 64, 1, 1, 0, 1), "wgrad2_kernel<1,1,4,2,2>"),    # layer1 conv1: M 64, Nn 256
-    ((2, 64, 30, 44, 64, 3, 1, 1, 1), "wgrad2_kernel<9,1,4,2,2>"),     # stem / layer1 3x3: M 64, Nn 576
-    ((1, 95, 19, 21, 40, 3, 2, 1, 1), "wgrad2_kernel<9,1,4,2,2>"),     # stride 2, ragged
+    ((2, 256, 24, 36, 64, 1, 1, 0, 1), "wgrad2_kernel<1,2,2,1,1>"),    # layer1 conv1: M 64, Nn 256 (one-wave tile)
+    ((2, 64, 30, 44, 64, 3, 1, 1, 1), "wgrad2_kernel<9,2,2,1,1>"),     # stem / layer1 3x3: M 64, Nn 576
     ((2, 12, 21, 33, 200, 3, 1, 2, 2), "wgrad2_kernel<9,4,2,2,2>"),    # Nn 108
     ((2, 5, 25, 31, 256, 3, 1, 1, 1), "wgrad2_kernel<9,4,1,2,2>"),     # Nn 45
 ]
