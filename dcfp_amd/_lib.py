@@ -19,7 +19,8 @@ _lock = threading.Lock()
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "dil", "Hout", "Wout")]
+                ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "dil", "Hout", "Wout",
+                 "x_pitch", "dy_pitch")]
 
 
 class EicEntry(C.Structure):
@@ -59,6 +60,7 @@ SIGNATURES = {
     "dcfp_conv2d_workspace_bytes": (_Z, [_D, _I]),
     "dcfp_conv2d_wp_layout": (_I, [_D, _I, C.POINTER(WpEntry)]),
     "dcfp_conv2d_permute_weights_multi_f32": (_I, [_P, _I, _L, _P]),
+    "dcfp_conv2d_pitch_supported": (_I, [_D]),
     "dcfp_conv2d_kernel_name": (_I, [_D, _I, C.c_char_p, _I]),
     "dcfp_conv2d_fwd_f32_nchw": (_I, [_D, _P, _P, _P, _P, _L, _P, _Z, _I, _P]),
     "dcfp_conv2d_fwd_fused_f32_nchw": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P]),
@@ -66,7 +68,7 @@ SIGNATURES = {
     "dcfp_conv2d_wgrad_f32_nchw": (_I, [_D, _P, _L, _P, _P, _P, _P, _Z, _P]),
     "dcfp_bn_workspace_bytes": (_Z, [_I, _I, _I]),
     "dcfp_bn_stats_f32": (_I, [_P, _L, _I, _I, _I, _P, _P, _R, _P, _Z, _P]),
-    "dcfp_bn_apply_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P, _L, _I, _I, _I, _P]),
+    "dcfp_bn_apply_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
     "dcfp_bn_bwd_reduce_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P,
                                     _P, _Z, _P]),
     "dcfp_bn_update_running_f32": (_I, [_P, _P, _I, _F, _F, _P, _P, _P, _P]),
@@ -76,7 +78,7 @@ SIGNATURES = {
     "dcfp_conv2d_fwd_stats_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _P, _Z, _I, _P]),
     "dcfp_bn_stats_from_partials_f32": (_I, [_P, _L, _I, _I, _P, _P, _R, _P]),
     "dcfp_bn_bwd_apply_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _P, _P, _F, _P, _I, _P, _P,
-                                   _I, _I, _I, _P]),
+                                   _I, _I, _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dcfp_rowsum_f32": (_I, [_P, _L, _P, _F, _I, _I, _I, _P]),

@@ -123,7 +123,8 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                 const float* __restrict__ var, const float* __restrict__ gamma,
                 const float* __restrict__ beta, float eps, const float* __restrict__ res,
                 int relu, float* __restrict__ y, long long y_nstride, int C, int HW,
-                int colchunks, int cols_per_block, unsigned long long* __restrict__ mask = nullptr) {
+                int colchunks, int cols_per_block, unsigned long long* __restrict__ mask = nullptr,
+                int W = 0, int y_pitch = 0) {
     const long long row = blockIdx.x / colchunks;
     const int chunk = blockIdx.x - (int)(row * colchunks);
     const int n = (int)(row / C), c = (int)(row - (long long)n * C);
@@ -131,7 +132,9 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
     const float mu = mean[c], g = gamma[c], b = beta[c];
     const float* xr = x + row * HW;
     const float* rr = res ? res + row * HW : nullptr;
-    float* yr = y + (long long)n * y_nstride + (long long)c * HW;
+    // y_pitch != 0: rows of W floats are written y_pitch floats apart (the tail behind each row is the caller's
+    // zero padding and is never touched); element i of the (n,c) plane then lives at (i / W) * y_pitch + i % W
+    float* yr = y + (long long)n * y_nstride + (long long)c * (y_pitch ? (long long)(HW / W) * y_pitch : HW);
     const int i0 = chunk * cols_per_block;
     int i1 = i0 + cols_per_block;
     if (i1 > HW) i1 = HW;
@@ -159,14 +162,16 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                     mw[0] = b0; mw[1] = b1; mw[2] = b2; mw[3] = b3;
                 }
             }
-            *reinterpret_cast<float4*>(yr + i) = o;
+            if (y_pitch) { const int h = i / W; *reinterpret_cast<float4*>(yr + h * y_pitch + (i - h * W)) = o; }
+            else *reinterpret_cast<float4*>(yr + i) = o;
         }
     } else {
         for (int i = i0 + threadIdx.x; i < i1; i += kThreads) {
             float o = bn_val(xr[i], mu, istd, g, b);
             if (rr) o += rr[i];
             if (relu) o = o > 0.f ? o : 0.f;
-            yr[i] = o;
+            if (y_pitch) { const int h = i / W; yr[h * y_pitch + (i - h * W)] = o; }
+            else yr[i] = o;
         }
     }
 }
@@ -344,7 +349,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xmu,
                     float inv_count_host, const float* __restrict__ count_dev,
                     float* __restrict__ dx, float* __restrict__ dres, int C,
-                    int HW, int colchunks, int cols_per_block) {
+                    int HW, int colchunks, int cols_per_block, int W, int dx_pitch) {
     const float inv_count = count_dev ? 1.0f / count_dev[0] : inv_count_host;
     const long long row = blockIdx.x / colchunks;
     const int chunk = blockIdx.x - (int)(row * colchunks);
@@ -359,7 +364,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
     const float* dyr = dy + (long long)n * dy_nstride + (long long)c * HW;
     const float* xr = x + row * HW;
     const float* yr = RELU == 1 ? y + (long long)n * y_nstride + (long long)c * HW : nullptr;
-    float* dxr = dx + row * HW;
+    float* dxr = dx + row * (dx_pitch ? (long long)(HW / W) * dx_pitch : HW);   // dx_pitch: as y_pitch of bn_apply
     float* drr = dres ? dres + row * HW : nullptr;
     const int i0 = chunk * cols_per_block;
     int i1 = i0 + cols_per_block;
@@ -388,7 +393,8 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
             o.y = (g.y - mean_dy - (xv.y - mu) * k) * gi;
             o.z = (g.z - mean_dy - (xv.z - mu) * k) * gi;
             o.w = (g.w - mean_dy - (xv.w - mu) * k) * gi;
-            *reinterpret_cast<float4*>(dxr + i) = o;
+            if (dx_pitch) { const int h = i / W; *reinterpret_cast<float4*>(dxr + h * dx_pitch + (i - h * W)) = o; }
+            else *reinterpret_cast<float4*>(dxr + i) = o;
             if (drr) *reinterpret_cast<float4*>(drr + i) = g;
         }
     } else {
@@ -396,7 +402,9 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
             float g = dyr[i];
             if (RELU == 1) g = yr[i] > 0.f ? g : 0.f;
             else if (RELU == 2) g = bn_val(xr[i], mu, istd, gm, bt) > 0.f ? g : 0.f;
-            dxr[i] = (g - mean_dy - (xr[i] - mu) * k) * gi;
+            const float o = (g - mean_dy - (xr[i] - mu) * k) * gi;
+            if (dx_pitch) { const int h = i / W; dxr[h * dx_pitch + (i - h * W)] = o; }
+            else dxr[i] = o;
             if (drr) drr[i] = g;
         }
     }
@@ -447,23 +455,26 @@ extern "C" int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C
 extern "C" int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
                                  const float* gamma, const float* beta, float eps,
                                  const float* residual, int relu, float* y, int64_t y_nstride,
-                                 int N, int C, int HW, dcfp_stream_t stream) {
+                                 int N, int C, int HW, int W, int y_pitch, dcfp_stream_t stream) {
     if (!x || !mean || !var || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0)
         return DCFP_E_BADDESC;
-    if (y_nstride == 0) y_nstride = (int64_t)C * HW;
+    if (y_pitch && (W <= 0 || HW % W != 0 || y_pitch < W)) return DCFP_E_BADDESC;
+    if (y_pitch == W) y_pitch = 0;
+    if (y_nstride == 0) y_nstride = (int64_t)C * (y_pitch ? (int64_t)(HW / W) * y_pitch : HW);
     const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
     const long long blocks = (long long)N * C * colchunks;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const bool vec = (HW % 4 == 0) && (y_nstride % 4 == 0) && dcfp_aligned16(x) &&
-                     dcfp_aligned16(y) && (!residual || dcfp_aligned16(residual));
+                     dcfp_aligned16(y) && (!residual || dcfp_aligned16(residual)) &&
+                     (!y_pitch || (W % 4 == 0 && y_pitch % 4 == 0));
     if (vec)
         hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
                            dcfp_s(stream), x, mean, var, gamma, beta, eps, residual, relu, y,
-                           (long long)y_nstride, C, HW, colchunks, kColsPerBlock);
+                           (long long)y_nstride, C, HW, colchunks, kColsPerBlock, nullptr, W, y_pitch);
     else
         hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
                            dcfp_s(stream), x, mean, var, gamma, beta, eps, residual, relu, y,
-                           (long long)y_nstride, C, HW, colchunks, kColsPerBlock);
+                           (long long)y_nstride, C, HW, colchunks, kColsPerBlock, nullptr, W, y_pitch);
     DCFP_RETURN_LAUNCH();
 }
 
@@ -536,12 +547,14 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
                                      const float* var, const float* gamma, const float* beta,
                                      float eps, const float* sum_dy, const float* sum_dy_xmu,
                                      float count, const float* count_dev, int relu, float* dx,
-                                     float* d_residual, int N, int C, int HW,
+                                     float* d_residual, int N, int C, int HW, int W, int dx_pitch,
                                      dcfp_stream_t stream) {
     if (!dy || !x || !mean || !var || !gamma || !sum_dy || !sum_dy_xmu || !dx || N <= 0 ||
         C <= 0 || HW <= 0 || (!count_dev && !(count > 0.f)))
         return DCFP_E_BADDESC;
     if (relu < 0 || relu > 3 || ((relu == 1 || relu == 3) && !y) || (relu == 2 && !beta)) return DCFP_E_BADDESC;
+    if (dx_pitch && (W <= 0 || HW % W != 0 || dx_pitch < W)) return DCFP_E_BADDESC;
+    if (dx_pitch == W) dx_pitch = 0;
     if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
     if (y_nstride == 0) y_nstride = (int64_t)C * HW;
     const int colchunks = (HW + kColsPerBlock - 1) / kColsPerBlock;
@@ -549,14 +562,15 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
     const bool vec = (HW % 4 == 0) && (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                      dcfp_aligned16(dy) && dcfp_aligned16(x) && dcfp_aligned16(dx) &&
-                     (relu != 1 || dcfp_aligned16(y)) && (!d_residual || dcfp_aligned16(d_residual));
+                     (relu != 1 || dcfp_aligned16(y)) && (!d_residual || dcfp_aligned16(d_residual)) &&
+                     (!dx_pitch || (W % 4 == 0 && dx_pitch % 4 == 0));
     const float inv_count = count > 0.f ? 1.0f / count : 0.f;
 #define LAUNCH_APP(V, R)                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<V, R>), dim3((unsigned)blocks), dim3(kThreads), 0,    \
                        dcfp_s(stream), dy, (long long)dy_nstride, x, y, (long long)y_nstride,     \
                        mean, var, gamma, beta, eps, sum_dy, sum_dy_xmu, inv_count, count_dev, dx, \
                        d_residual, C,                                                             \
-                       HW, colchunks, kColsPerBlock)
+                       HW, colchunks, kColsPerBlock, W, dx_pitch)
     if (relu == 3 && !(vec && HW % 256 == 0)) return DCFP_E_UNSUPPORTED;
     if (vec) { if (relu == 3) LAUNCH_APP(true, 3); else if (relu == 2) LAUNCH_APP(true, 2); else if (relu == 1) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
     else     { if (relu == 2) LAUNCH_APP(false, 2); else if (relu == 1) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }

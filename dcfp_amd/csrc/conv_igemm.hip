@@ -27,9 +27,12 @@ int check_desc(const DcfpConvDesc* d) {
     const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
     if (ho != d->Hout || wo != d->Wout || ho <= 0 || wo <= 0) return DCFP_E_BADDESC;
+    if ((d->x_pitch != 0 && (d->x_pitch < d->W || (d->x_pitch & 3))) ||
+        (d->dy_pitch != 0 && (d->dy_pitch < d->Wout || (d->dy_pitch & 3))))
+        return DCFP_E_BADDESC;
     // buffer descriptors address one image / the weight tensor with 31-bit byte offsets
-    if ((long long)d->Cin * d->H * d->W >= (1LL << 29) ||
-        (long long)d->Cout * d->Hout * d->Wout >= (1LL << 29) ||
+    if ((long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W) >= (1LL << 29) ||
+        (long long)d->Cout * d->Hout * (d->dy_pitch ? d->dy_pitch : d->Wout) >= (1LL << 29) ||
         (long long)d->Cout * d->Cin * d->KH * d->KW >= (1LL << 29))
         return DCFP_E_UNSUPPORTED;
     return DCFP_OK;
@@ -48,7 +51,8 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale = nullptr, const float* shift = nullptr,
-                    const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0);
+                    const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0,
+                    int in_pitch = 0);
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 bool dcfp_igemm2_persist();
@@ -106,8 +110,10 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     if (dcfp_igemm2_dma_shape(d->KH * d->KW, M, Ck, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd, d->pad, HiWi,
                               pass == DCFP_CONV_FWD ? d->Wout : d->W)) {
         if (d->KH == 1 && dcfp_igemm2_persist()) return snprintf(buf, buf_len, "igemm2_dma1p_kernel");   // <ACC>
+        const int src_pitch = pass == DCFP_CONV_FWD ? d->x_pitch : d->dy_pitch;
+        const bool pitched = src_pitch && src_pitch != (pass == DCFP_CONV_FWD ? d->W : d->Wout);
         return snprintf(buf, buf_len, "igemm2_dma_kernel<%d,%s>", d->KH * d->KW,
-                        (d->KH == 3 && ((d->pad | d->dil) & 3) != 0) ? "true" : "false");   // <TAPS, MIXED>
+                        (d->KH == 3 && ((d->pad | d->dil) & 3) != 0 && !pitched) ? "true" : "false");   // <TAPS, MIXED>
     }
     return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW, dcfp_igemm2_cfg_args(M, px, sd));
 }
@@ -120,16 +126,17 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     if (rc) return rc;
     if (!x || !w || !y) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (d->x_pitch && d->x_pitch != d->W && math_bf16x3()) return DCFP_E_UNSUPPORTED;
     if (!bias && igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                                y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                                d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, -d->pad, d->dil, 0,
                                workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0, wp_valid);
-    return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
+    return dcfp_igemm2_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), w, d->Cin * T, T, bias, y,
                            y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                            d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
                            d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0,
-                           nullptr, wp_valid);
+                           nullptr, wp_valid, d->x_pitch);
 }
 
 // Forward conv that also emits BatchNorm batch-statistics partials of its output (see
@@ -150,11 +157,11 @@ extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float
     if (!x || !w || !y || !stat_partials) return DCFP_E_BADDESC;
     if (dcfp_conv2d_fwd_stat_slots(d, y, y_nstride) <= 0) return DCFP_E_UNSUPPORTED;
     const int T = d->KH * d->KW;
-    return dcfp_igemm2_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
+    return dcfp_igemm2_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), w, d->Cin * T, T, nullptr, y,
                            y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                            d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
                            d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr,
-                           nullptr, 0, stat_partials, wp_valid);
+                           nullptr, 0, stat_partials, wp_valid, d->x_pitch);
 }
 
 extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy,
@@ -165,17 +172,18 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (rc) return rc;
     if (!dy || !w || !dx) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (d->dy_pitch && d->dy_pitch != d->Wout && math_bf16x3()) return DCFP_E_UNSUPPORTED;
     if (igemm3_ok(d->Cin, (long long)d->N * d->H * d->W, 1, d->stride))
         return dcfp_igemm3_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
                                T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
                                d->Cout, T, d->Hout, d->Wout, d->H, d->W, d->pad, -d->dil,
                                accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr,
                                nullptr, 0, wp_valid);
-    return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
+    return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * (d->dy_pitch ? d->dy_pitch : d->Wout), w,
                            T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
                            d->Cout, T, d->Hout, d->Wout, d->H, d->W, 1, d->stride, d->pad, -d->dil,
                            accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0,
-                           nullptr, wp_valid);
+                           nullptr, wp_valid, d->dy_pitch);
 }
 
 // Inference: conv + folded eval-mode BatchNorm (+residual) (+ReLU) in the conv epilogue.
@@ -225,4 +233,18 @@ extern "C" int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, i
     if (n == 0 || total_blocks == 0) return DCFP_OK;
     if (!table || n < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return DCFP_E_BADDESC;
     return dcfp_igemm2_permute_multi(table, n, total_blocks, dcfp_s(stream));
+}
+
+bool dcfp_wgrad_pitch_ok(const DcfpConvDesc* d);   // conv_wgrad.hip
+
+extern "C" int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d) {
+    if (check_desc(d) != DCFP_OK || math_bf16x3()) return 0;
+    if (d->KH != 3 || d->stride != 1 || d->pad != d->dil || d->Hout != d->H || d->Wout != d->W) return 0;
+    const int xp = d->x_pitch ? d->x_pitch : d->W, dp = d->dy_pitch ? d->dy_pitch : d->Wout;
+    if (xp < d->W + d->pad && xp != d->W) return 0;
+    if (dp < d->Wout + d->pad && dp != d->Wout) return 0;
+    const long long pxo = (long long)d->N * d->Hout * d->Wout, pxi = (long long)d->N * d->H * d->W;
+    if (!dcfp_igemm2_dma_shape(9, d->Cout, d->Cin, d->Hout * d->Wout, pxo, 1, 1, -d->pad, d->H * d->W, d->Wout)) return 0;
+    if (!dcfp_igemm2_dma_shape(9, d->Cin, d->Cout, d->H * d->W, pxi, 1, 1, d->pad, d->Hout * d->Wout, d->W)) return 0;
+    return dcfp_wgrad_pitch_ok(d) ? 1 : 0;
 }

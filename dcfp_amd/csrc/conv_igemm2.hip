@@ -612,7 +612,8 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int HiWi = p.Hi * p.Wi;
+    const int HiWi = p.Hi * p.in_pitch;             // channel stride of the B source (in_pitch == Wi when dense)
+    const int padw = p.in_pitch - p.Wi;              // zero floats behind every source row
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // wave w copies k-rows 4w .. 4w+3 of both operands
     unsigned a_voff[4], b_row[4];
@@ -649,15 +650,20 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         tap_quads = !MIXED || (offw & 3) == 0 || (t2d && t_ow0 + offw >= 0 && t_ow0 + tcols - 1 + offw < p.Wi);
         {
             const int hh = q_oh + offh, ww = q_ow + offw;
-            const bool ok = q_in && hh >= 0 && hh < p.Hi && ww >= 0 && ww + 3 < p.Wi;
-            boff4 = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+            // pitched source: a quad may start up to padw floats left of the row (the previous row's zero tail,
+            // or before the buffer: out of range -> zeros) and end up to padw floats behind it
+            // (offsets are relative to padw floats BEFORE the image - the descriptor below starts there - so that
+            // a quad hanging over the left end of row 0 of channel 0 has a non-negative offset: a dwordx4 whose
+            // first dword's offset wrapped below zero is dropped as a whole, the valid half included)
+            const bool ok = q_in && hh >= 0 && hh < p.Hi && ww >= -padw && ww + 3 < p.Wi + padw;
+            boff4 = ok ? (unsigned)(hh * p.in_pitch + ww + padw) * 4u : kOob;
         }
         if constexpr (MIXED) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int hh = s_oh[e] + offh, ww = s_ow[e] + offw;
                 const bool ok = s_in[e] && hh >= 0 && hh < p.Hi && ww >= 0 && ww < p.Wi;
-                boff1[e] = ok ? (unsigned)(hh * p.Wi + ww) * 4u : kOob;
+                boff1[e] = ok ? (unsigned)(hh * p.in_pitch + ww + padw) * 4u : kOob;
             }
         }
     };
@@ -672,7 +678,9 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         return d;
     };
     const u32x4 a_desc = make_desc(p.wp, 0x7ffffffcu);
-    const u32x4 b_desc = make_desc(p.in + (long long)img * p.in_nstride, (unsigned)(p.Ck * HiWi) * 4u);
+    // pitched source: the padw floats in front of an image are readable zeros by contract (the previous image's
+    // last row tail, or the buffer's leading margin)
+    const u32x4 b_desc = make_desc(p.in + (long long)img * p.in_nstride - padw, (unsigned)(p.Ck * HiWi + padw) * 4u);
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
     auto issue = [&](int buf) {      // copy tile (ld_t, ld_cb) into LDS buffer `buf`, then step the loader
         const unsigned a_s = (unsigned)((ld_t * p.CkP + ld_cb * BK) * p.Mpad + m0) * 4u;
@@ -971,7 +979,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale, const float* shift, const float* residual, int relu,
-                    float* stat_part, int wp_valid) {
+                    float* stat_part, int wp_valid, int in_pitch) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
@@ -981,10 +989,18 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
+    p.in_pitch = in_pitch > 0 ? in_pitch : Wi;
+    const bool pitched = p.in_pitch != Wi;
+    if (pitched) {   // only the 9-tap LDS-DMA kernel reads pitched sources; every tap's column shift must fit the tail
+        const int reach = off0 < 0 ? -off0 : off0;      // |first tap shift|; the last is off0 + 2*offstep = -off0 (pad = dil)
+        if (T != 9 || p.in_pitch < Wi + reach || off0 + 2 * offstep != -off0 || (p.in_pitch & 3) ||
+            !dcfp_igemm2_dma_shape(T, M, Ck, Ho * Wo, px, sn, sd, off0, Hi * Wi, Wo) || bias || scale || relu)
+            return DCFP_E_UNSUPPORTED;
+    }
     {
         static const int t2d = [] { const char* e = getenv("DCFP_IGEMM_2D"); return e ? atoi(e) : 5; }();   // 0: off; 4 / 5: 16 / 32 columns
         const bool fits = (t2d == 4 || t2d == 5) && Hi % (256 >> t2d) == 0 && Wi % (1 << t2d) == 0;
-        p.tile2d = (fits && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
+        p.tile2d = (fits && !pitched && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
     }
     p.tiles_per_img = (p.P + c.bn - 1) / c.bn;
     p.Hc = p.Wc = p.tiles_per_phase = p.zfold = 0;
@@ -1031,7 +1047,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
             if (dcfp_igemm2_persist()) return dcfp_igemm2p_launch(p, stream);
             return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
         }
-        if (((off0 | offstep) & 3) == 0)
+        if (((off0 | offstep) & 3) == 0 || pitched)    // pitched rows: shifted quads need no border handling
             return accumulate ? launch(igemm2_dma_kernel<9, false, true>) : launch(igemm2_dma_kernel<9, false, false>);
         return accumulate ? launch(igemm2_dma_kernel<9, true, true>) : launch(igemm2_dma_kernel<9, true, false>);
     }

@@ -42,6 +42,7 @@ struct WgradParams {
     int Kpix;
     int kchunk, splits, tiles_m, tiles_n;
     int quad_ok;  // Wo % 4 == 0: the 4 pixels of a quad share (img, oh)
+    int x_pitch, dy_pitch;   // row pitches (floats) of x / dy; > W / Wo: rows carry a zero tail (wgrad_dma_kernel only)
 };
 
 constexpr unsigned kOob = 0x80000000u;      // > any record count: buffer loads return 0
@@ -462,7 +463,9 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     const int wm = wid / WN, wn = wid - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int img0 = kbeg / p.P;
-    const int HW = p.H * p.W;
+    const int HW = p.H * p.x_pitch;                  // channel stride of x (x_pitch == W when dense)
+    const int dyP = p.Ho * p.dy_pitch;               // channel stride of dy
+    const int padx = p.x_pitch - p.W;                // zero floats behind every row of x
     typedef unsigned u32x4 __attribute__((vector_size(16)));
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto make_desc = [](const void* base) {
@@ -471,7 +474,9 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         return d;
     };
     const u32x4 a_desc = make_desc(p.dy + (long long)img0 * p.dy_nstride);
-    const u32x4 b_desc = make_desc(p.x + (long long)img0 * p.x_nstride);
+    // pitched x: offsets are taken from padx floats before the image (readable zeros by contract), so that a quad
+    // hanging over the left end of the very first row keeps a non-negative offset
+    const u32x4 b_desc = make_desc(p.x + (long long)img0 * p.x_nstride - padx);
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
 
     // ---- A (dy): instruction q of this wave copies rows 64*wid + 16q + (lane >> 2); the lane's slot
@@ -482,7 +487,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     for (int q = 0; q < 4; ++q) {
         int m = m0 + 64 * wid + 16 * q + (lane >> 2);
         m = m < p.M ? m : p.M - 1;
-        a_voff[q] = (unsigned)(m * p.P + 4 * gq) * 4u;
+        a_voff[q] = (unsigned)(m * dyP + 4 * gq) * 4u;
     }
     // ---- B (x at the row's tap shift): quad copies use the same lane -> (row, quad) map; dword copies
     // (MIXED) cover rows 64*wid + 16q + 4e + (lane >> 4), slot (lane >> 2) & 3 -> quad slot ^ e, pixel lane & 3
@@ -512,7 +517,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     }
     auto issue = [&](int buf) {
         // (uniform values; readfirstlane makes the compiler keep them in SGPRs for the asm operands)
-        const unsigned a_s = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.dy_nstride + c_oh * p.Wo + c_ow) * 4u);
+        const unsigned a_s = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.dy_nstride + c_oh * p.dy_pitch + c_ow) * 4u);
         const unsigned b_img = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.x_nstride) * 4u);
         const int oh = c_oh, ow = c_ow;
         static_for<0, 4>([&](auto q_) {
@@ -528,14 +533,15 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
             const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 16 * q) * BK) * 4u);
             const int hh = oh + bq_dh[q], ww = ow + 4 * gq + bq_dw[q];
             const bool row_ok = hh >= 0 && hh < p.H;
-            const bool ok = row_ok && ww >= 0 && ww + 3 < p.W;
+            // pitched x: the quad may hang over a row end into the zero tail (of this or the previous row)
+            const bool ok = row_ok && ww >= -padx && ww + 3 < p.W + padx;
             const unsigned bs_ = b_img;
             const u32x4 bd = b_desc;
             bool quads = true;
             if constexpr (MIXED)      // a quad that straddles the image border: only on a row's first / last K-step
                 quads = __ballot(row_ok && !ok && ww > -4 && ww < p.W) == 0;
             if (quads) {             // 16-byte copies; with a shifted tap the source is only 4/8-byte aligned
-                const unsigned bv = ok ? (unsigned)(bq_c[q] + hh * p.W + ww) * 4u : kOob;
+                const unsigned bv = ok ? (unsigned)(bq_c[q] + hh * p.x_pitch + ww + padx) * 4u : kOob;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                              :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
             } else if constexpr (MIXED) {
@@ -545,7 +551,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
                     const unsigned le = lb + (unsigned)(4 * e * BK) * 4u;
                     const int h1 = oh + bd_dh[qe], w1 = ow + 4 * (gd ^ e) + (lane & 3) + bd_dw[qe];
                     const bool ok1 = h1 >= 0 && h1 < p.H && w1 >= 0 && w1 < p.W;
-                    const unsigned bv = ok1 ? (unsigned)(bd_c[qe] + h1 * p.W + w1) * 4u : kOob;
+                    const unsigned bv = ok1 ? (unsigned)(bd_c[qe] + h1 * p.x_pitch + w1 + padx) * 4u : kOob;
                     const unsigned bs2 = bs_;
                     const u32x4 bd2 = bd;
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
@@ -688,8 +694,11 @@ int check_desc(const DcfpConvDesc* d) {
     const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
     if (ho != d->Hout || wo != d->Wout || ho <= 0 || wo <= 0) return DCFP_E_BADDESC;
-    if ((long long)d->Cin * d->H * d->W >= (1LL << 29) ||
-        (long long)d->Cout * d->Hout * d->Wout >= (1LL << 29) ||
+    if ((d->x_pitch != 0 && (d->x_pitch < d->W || (d->x_pitch & 3))) ||
+        (d->dy_pitch != 0 && (d->dy_pitch < d->Wout || (d->dy_pitch & 3))))
+        return DCFP_E_BADDESC;
+    if ((long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W) >= (1LL << 29) ||
+        (long long)d->Cout * d->Hout * (d->dy_pitch ? d->dy_pitch : d->Wout) >= (1LL << 29) ||
         (long long)d->Cout * d->Cin * d->KH * d->KW >= (1LL << 29))
         return DCFP_E_UNSUPPORTED;
     return DCFP_OK;
@@ -756,13 +765,25 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 
 }  // namespace
 
+// pitched operands: the LDS-DMA kernel only, 3x3 with pad = dil and a tail that covers the column shifts
+bool dcfp_wgrad_pitch_ok(const DcfpConvDesc* d) {
+    if (check_desc(d) != DCFP_OK) return false;
+    const Plan pl = make_plan(d);
+    if (wgrad3_ok(d, pl.cfg) || !wgrad_dma_ok(d, pl.cfg)) return false;
+    const int xp = d->x_pitch ? d->x_pitch : d->W;
+    if (xp != d->W && (d->KH != 3 || d->pad != d->dil || xp < d->W + d->pad)) return false;
+    // 31-bit byte offsets relative to the first image of a split: checked in the launcher with the pitched strides
+    return true;
+}
+
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
                        pl.cfg == 4 ? "4,1,2,2" : "2,2,1,1";
     if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
     if (wgrad_dma_ok(d, pl.cfg))
-        return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,%s>", d->KH * d->KW, wgrad_dma_mixed(d) ? "true" : "false");
+        return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,%s>", d->KH * d->KW,
+                        (wgrad_dma_mixed(d) && !(d->x_pitch && d->x_pitch != d->W)) ? "true" : "false");
     return snprintf(buf, buf_len, "wgrad2_kernel<%d,%s>", d->KH * d->KW, args);
 }
 
@@ -791,8 +812,12 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     WgradParams p;
     p.dy = dy; p.x = x;
     p.out = pl.splits > 1 ? static_cast<float*>(workspace) : dw;
-    p.dy_nstride = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout;
-    p.x_nstride = (long long)d->Cin * d->H * d->W;
+    p.x_pitch = d->x_pitch ? d->x_pitch : d->W;
+    p.dy_pitch = d->dy_pitch ? d->dy_pitch : d->Wout;
+    const bool pitched = p.x_pitch != d->W || p.dy_pitch != d->Wout;
+    if (pitched && !dcfp_wgrad_pitch_ok(d)) return DCFP_E_UNSUPPORTED;
+    p.dy_nstride = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * p.dy_pitch;
+    p.x_nstride = (long long)d->Cin * d->H * p.x_pitch;
     p.N = d->N; p.M = d->Cout; p.Cin = d->Cin; p.Nn = d->Cin * T;
     p.H = d->H; p.W = d->W; p.Ho = d->Hout; p.Wo = d->Wout; p.P = d->Hout * d->Wout;
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -812,9 +837,10 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     else if (wgrad_dma_ok(d, pl.cfg)) {
         const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
         if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+        // (pitched x: every shifted quad reads data or the rows' zero tails - the un-mixed kernel does it all)
         rc = T == 1 ? launch_dma<1, false>(p, blocks, dcfp_s(stream))
-                    : wgrad_dma_mixed(d) ? launch_dma<9, true>(p, blocks, dcfp_s(stream))
-                                         : launch_dma<9, false>(p, blocks, dcfp_s(stream));
+                    : (wgrad_dma_mixed(d) && p.x_pitch == d->W) ? launch_dma<9, true>(p, blocks, dcfp_s(stream))
+                                                                 : launch_dma<9, false>(p, blocks, dcfp_s(stream));
     } else
         rc = T == 1 ? launch_taps<1>(p, pl, dcfp_s(stream)) : launch_taps<9>(p, pl, dcfp_s(stream));
     if (rc) return rc;

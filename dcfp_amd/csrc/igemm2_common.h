@@ -21,6 +21,8 @@ struct Igemm2Params {
     int accumulate, vec_store;
     int tile2d;         // igemm2_dma_kernel<9, true>: 0, or log2(columns) of a 2-D pixel tile (8 rows x 32 or 16 x 16)
     int Hc, Wc, tiles_per_phase;   // strided dgrad (sd > 1): coarse grid ceil(Ho/sd) x ceil(Wo/sd) of one output phase
+    int in_pitch;       // row pitch (floats) of the B source; > Wi: rows carry a zero tail of in_pitch - Wi floats, so a
+                        // shifted 16-byte quad may hang over either row end and still read zeros (no border handling)
     int zfold;          // strided dgrad of a 1x1 conv: only phase `zfold - 1` has a tap; its tiles also write the zeros
     float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
 };

@@ -104,7 +104,7 @@ def bottleneck(blk, x):
             raise RuntimeError("dcfp_amd: downsample stride differs from conv2 stride")
         tensors += [dconv.weight, dbn.weight, dbn.bias]
         bns.append(dbn)
-    cfg = {"stride": stride, "dil": dil, "bn": [_bn_args(b) for b in bns]}
+    cfg = {"stride": stride, "dil": dil, "bn": [_bn_args(b) for b in bns], "owner": blk}
     return ops.bottleneck(x, cfg, tensors)
 
 

@@ -95,17 +95,67 @@ def _batch_strided(t):
     return t, Cc * H * W
 
 
+def _pitch_of(t):
+    """Row pitch of a [N,C,H,W] tensor whose rows are dense but stride(2) > W (a [..., :W] view of a buffer with
+    padded rows, channels H*pitch and images C*H*pitch apart); 0 for anything else (dense included)."""
+    N, Cc, H, W = t.shape
+    st = t.stride()
+    if st[3] == 1 and st[2] > W and st[2] % 4 == 0 and st[1] == H * st[2] and (N == 1 or st[0] == Cc * H * st[2]):
+        return st[2]
+    return 0
+
+
+_PITCH_BUFFERS = {}
+
+
+def pitched_buffer(shape, pitch, key, device):
+    """[N,C,H,W] view (rows `pitch` floats apart) of a persistent zero-initialised buffer: the kernels write the
+    W live floats of a row only, so the tail stays zero for as long as the buffer lives (no per-step fill)."""
+    k = (key, tuple(shape), pitch, str(device))
+    buf = _PITCH_BUFFERS.get(k)
+    if buf is None:
+        buf = new_pitched(shape, pitch, device)
+        _PITCH_BUFFERS[k] = buf
+    return buf
+
+
+def new_pitched(shape, pitch, device):
+    """Fresh zeroed row-pitched [N,C,H,W] view.  The allocation starts with a margin of zeros (the contract of
+    DcfpConvDesc.x_pitch: the pitch - W floats in front of the first element are readable zeros)."""
+    N, Cc, H, W = shape
+    lead = 64                                            # floats; keeps the view 256-byte aligned
+    flat = torch.zeros(lead + N * Cc * H * pitch, dtype=torch.float32, device=device)
+    return flat[lead:].view(N, Cc, H, pitch)[..., :W]
+
+
+# The 3x3 convs whose taps shift columns by a non-multiple of 4 (dilation 1 / 2) read their shifted operand from a
+# row-pitched tensor with a zero tail instead of handling image borders with 4-byte copies (include/dcfp_hip.h
+# DcfpConvDesc.x_pitch).  DCFP_PITCHED=0: dense operands everywhere.
+PITCHED = os.environ.get("DCFP_PITCHED", "1") not in ("0",)
+
+
+def conv_pitch(xshape, wshape, stride, pad, dil):
+    """Row pitch to use for the x / dy operands of this conv (0: keep them dense)."""
+    if not PITCHED or wshape[2] != 3 or stride != 1 or pad != dil or ((pad | dil) & 3) == 0:
+        return 0
+    W = xshape[3]
+    pitch = W + (pad + 3) // 4 * 4
+    d = _desc(xshape, wshape, stride, pad, dil, pitch, pitch)
+    return pitch if _lib.lib().dcfp_conv2d_pitch_supported(C.byref(d)) else 0
+
+
 def conv_out_size(size, k, stride, pad, dil):
     return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _desc(xshape, wshape, stride, pad, dil):
+def _desc(xshape, wshape, stride, pad, dil, x_pitch=0, dy_pitch=0):
     N, Cin, H, W = xshape
     Cout, Cin2, KH, KW = wshape
     if Cin2 != Cin:
         raise RuntimeError(f"conv2d: weight expects {Cin2} input channels, got {Cin} (groups unsupported)")
     d = ConvDesc(N, Cin, H, W, Cout, KH, KW, stride, pad, dil,
-                 conv_out_size(H, KH, stride, pad, dil), conv_out_size(W, KW, stride, pad, dil))
+                 conv_out_size(H, KH, stride, pad, dil), conv_out_size(W, KW, stride, pad, dil),
+                 x_pitch, dy_pitch)
     return d
 
 
@@ -220,8 +270,11 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run
     (a BnRunning) lets the kernel that finalises them also update that BatchNorm's running statistics.
     out: optional [N, Cout, Ho, Wo] destination, may be a channel slice of a wider tensor (ASPP concat)."""
     _require(x, "x"); _require(w, "weight")
-    x = x.contiguous(); w = w if w.is_contiguous() else w.contiguous()
-    d = _desc(x.shape, w.shape, stride, pad, dil)
+    xp = _pitch_of(x)
+    if not xp:
+        x = x.contiguous()
+    w = w if w.is_contiguous() else w.contiguous()
+    d = _desc(x.shape, w.shape, stride, pad, dil, xp, 0)
     yns = 0
     if out is None:
         y = torch.empty((d.N, d.Cout, d.Hout, d.Wout), dtype=torch.float32, device=x.device)
@@ -256,8 +309,12 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
     """dx = conv_transpose(dy, w); with accumulate, `out` (+)= the result in place."""
     _require(dy, "dy")
     w = w if w.is_contiguous() else w.contiguous()
-    d = _desc(xshape, w.shape, stride, pad, dil)
-    dy, ns = _batch_strided(dy)
+    dp = _pitch_of(dy)
+    d = _desc(xshape, w.shape, stride, pad, dil, 0, dp)
+    if dp:
+        ns = dy.stride(0)
+    else:
+        dy, ns = _batch_strided(dy)
     if out is not None:
         if tuple(out.shape) != tuple(xshape) or not out.is_contiguous():
             raise RuntimeError("conv2d_dgrad: out must be a contiguous tensor of the input shape")
@@ -276,9 +333,14 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
 def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=None):
     """(dw, db); dw / db: optional destinations (the gradient arena's views)."""
     _require(dy, "dy"); _require(x, "x")
-    x = x.contiguous()
-    d = _desc(x.shape, wshape, stride, pad, dil)
-    dy, ns = _batch_strided(dy)
+    xp, dp = _pitch_of(x), _pitch_of(dy)
+    if not xp:
+        x = x.contiguous()
+    d = _desc(x.shape, wshape, stride, pad, dil, xp, dp)
+    if dp:
+        ns = dy.stride(0)
+    else:
+        dy, ns = _batch_strided(dy)
     L = _lib.lib()
     nbytes = L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_WGRAD)
     ws = _workspace("wgrad", nbytes, x.device)
@@ -359,19 +421,20 @@ def bn_apply(x, mean, var, gamma, beta, eps, residual=None, relu=False, out=None
     x = x.contiguous()
     if residual is not None:
         residual = residual.contiguous()
-    yns = 0
+    yns, ypitch = 0, 0
     if out is None:
         y = torch.empty_like(x)
-    else:           # e.g. a channel slice of the ASPP concat tensor (aspp.py:77)
+    else:           # a channel slice of the ASPP concat tensor (aspp.py:77), or a row-pitched buffer
         y = out
         st = y.stride()
-        if tuple(y.shape) != tuple(x.shape) or st[3] != 1 or st[2] != W or st[1] != H * W:
-            raise RuntimeError("bn_apply: out must have dense images")
+        ypitch = _pitch_of(y)
+        if tuple(y.shape) != tuple(x.shape) or (not ypitch and (st[3] != 1 or st[2] != W or st[1] != H * W)):
+            raise RuntimeError("bn_apply: out must have dense images or be a row-pitched buffer")
         yns = st[0]
     nbytes = (8.0 + (4.0 if residual is not None else 0.0)) * x.numel()
     _timed("bn_apply", None, nbytes, lambda: check(
         _lib.lib().dcfp_bn_apply_f32(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), float(eps),
-                                     _p(residual), int(relu), _p(y), yns, N, Cc, H * W, _stream()),
+                                     _p(residual), int(relu), _p(y), yns, N, Cc, H * W, W, ypitch, _stream()),
         "bn_apply"))
     return y
 
@@ -418,10 +481,18 @@ def bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu, dgamma=None, dbet
     return s1, s2, dgamma
 
 
-def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_residual):
+def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_residual, dx_out=None):
+    """dx_out: optional row-pitched destination (pitched_buffer) for dx."""
     N, Cc, H, W = x.shape
     dy, dns = _batch_strided(dy)
-    dx = torch.empty_like(x)
+    dxp = 0
+    if dx_out is not None:
+        dxp = _pitch_of(dx_out)
+        if tuple(dx_out.shape) != tuple(x.shape) or not dxp:
+            raise RuntimeError("bn_bwd_apply: dx_out must be a row-pitched buffer of x's shape")
+        dx = dx_out
+    else:
+        dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual else None
     nbytes = (12.0 + (4.0 if relu == 1 else 0.125 if relu == 3 else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
     count_dev = count if isinstance(count, torch.Tensor) else None   # SyncBN: global count on device
@@ -429,7 +500,7 @@ def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, wan
     _timed("bn_bwd_apply", None, nbytes, lambda: check(
         _lib.lib().dcfp_bn_bwd_apply_f32(_p(dy), dns, _p(x), _p(y) if relu in (1, 3) else None, 0, _p(mean),
                                          _p(var), _p(gamma), _p(beta), float(eps), _p(s1), _p(s2), count_host,
-                                         _p(count_dev), int(relu), _p(dx), _p(dres), N, Cc, H * W,
+                                         _p(count_dev), int(relu), _p(dx), _p(dres), N, Cc, H * W, W, dxp,
                                          _stream()),
         "bn_bwd_apply"))
     return dx, dres
@@ -590,17 +661,17 @@ def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None
     return (s1, s2, work, relu, y, dgamma, dbeta)
 
 
-def bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res):
+def bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res, dx_out=None):
     s1, s2, work, relu, y, dgamma, dbeta = red
     if work is not None:
         work.wait()
     mean, var, count = state[:3]
-    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_res)
+    dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_res, dx_out)
     return dx, dgamma, dbeta, dres
 
 
 def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res, gparam=None, bparam=None,
-                     between=None):
+                     between=None, dx_out=None):
     """Shared backward: returns (dx, dgamma, dbeta, dres).  dgamma/dbeta are this rank's sums (None when
     they went straight into the gradient arena; the gradient all-reduce averages them); under SyncBN the
     sums entering dx are global.  `y` is only needed for the ReLU mask of a BN that had a residual input;
@@ -609,7 +680,7 @@ def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res
     that hides the exchange."""
     red = bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam, bparam, eps)
     mid = between() if between is not None else None
-    out = bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res)
+    out = bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res, dx_out)
     return out + ((mid,) if between is not None else ())
 
 
@@ -666,7 +737,7 @@ class BottleneckFn(torch.autograd.Function):
         stride, dil = cfg["stride"], cfg["dil"]
         fuse = FUSE_BN_STATS   # each conv hands the batch statistics of its output to the BatchNorm behind it
 
-        def conv_bn(inp, wgt, a, g, b, st=1, pd=0, dl=1, relu=True, res=None, want_mask=False):
+        def conv_bn(inp, wgt, a, g, b, st=1, pd=0, dl=1, relu=True, res=None, want_mask=False, out=None):
             rm, rv, training, momentum, eps, sync, nbt = a
             stats = None
             if fuse and training:
@@ -677,10 +748,36 @@ class BottleneckFn(torch.autograd.Function):
             else:
                 c = conv2d_fwd(inp, wgt, None, st, pd, dl)
             y, state = bn_forward_impl(c, g, b, rm, rv, res, relu, training, momentum, eps, sync, nbt=nbt,
-                                       stats=stats, want_mask=want_mask)
+                                       stats=stats, want_mask=want_mask, out=out)
             return c, y, state
 
-        c1, y1, st1 = conv_bn(x, w1, bnargs[0], g1, b1)
+        # conv2 with dilation 1 / 2: its input y1 (and, in backward, the gradient of its output) are kept
+        # row-pitched with a zero tail, so the 3x3 kernels copy every shifted quad without border handling.
+        # y1 lives until this block's backward: one persistent buffer per block (cfg["owner"]), guarded by a
+        # busy flag (a second forward before the backward gets a fresh buffer).
+        N_, _, H_, W_ = x.shape
+        y1_shape = (N_, w1.shape[0], H_, W_)
+        pitch = conv_pitch(y1_shape, tuple(w2.shape), stride, dil, dil)
+        y1_out, owner = None, cfg.get("owner")
+        if pitch:
+            slot = getattr(owner, "_dcfp_pitch", None) if owner is not None else None
+            if slot is not None and not slot["busy"] and tuple(slot["y1"].shape) == y1_shape and _pitch_of(slot["y1"]) == pitch \
+                    and slot["y1"].device == x.device:
+                y1_out = slot["y1"]
+            else:
+                y1_out = new_pitched(y1_shape, pitch, x.device)
+                if owner is not None and (slot is None or not slot["busy"]):
+                    slot = {"y1": y1_out, "busy": False}
+                    owner._dcfp_pitch = slot
+                else:
+                    slot = None
+            if slot is not None:
+                slot["busy"] = True
+            ctx.pitch_slot = slot
+        else:
+            ctx.pitch_slot = None
+        ctx.pitch = pitch
+        c1, y1, st1 = conv_bn(x, w1, bnargs[0], g1, b1, out=y1_out)
         c2, y2, st2 = conv_bn(y1, w2, bnargs[1], g2, b2, stride, dil, dil)
         if has_ds:
             wd, gd, bd = tensors[9:]
@@ -736,8 +833,9 @@ class BottleneckFn(torch.autograd.Function):
         d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], True)
         d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
         # conv3's weight gradient does not feed bn2: it runs between bn2's reduction and its dx
+        dc2_out = pitched_buffer(tuple(c2.shape), ctx.pitch, "d_c2", c2.device) if ctx.pitch else None
         d_c2, dg2, db2, _, dw3 = bn_backward_impl(d_y2, c2, None, g2, b2, st2, True, training[1], eps[1], False,
-                                                  between=wg(d_c3, y2, w3))
+                                                  between=wg(d_c3, y2, w3), dx_out=dc2_out)
         d_y1 = conv2d_dgrad(d_c2, w2, tuple(y1.shape), stride, dil, dil)
         d_c1, dg1, db1, _, dw2 = bn_backward_impl(d_y1, c1, None, g1, b1, st1, True, training[0], eps[0], False,
                                                   between=wg(d_c2, y1, w2, stride, dil, dil))
@@ -757,6 +855,8 @@ class BottleneckFn(torch.autograd.Function):
             dx = conv2d_dgrad(d_c1, w1, tuple(x.shape), 1, 0, 1, out=dx, accumulate=True)
         else:
             dx = None
+        if ctx.pitch_slot is not None:
+            ctx.pitch_slot["busy"] = False      # y1's buffer may be reused by the next forward of this block
         return (dx, None) + tuple(grads)
 
 

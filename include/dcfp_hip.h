@@ -53,6 +53,18 @@ typedef struct DcfpConvDesc {
     int32_t Cout, KH, KW;       /* weight [Cout,Cin,KH,KW]             */
     int32_t stride, pad, dil;   /* same in h and w                     */
     int32_t Hout, Wout;         /* output [N,Cout,Hout,Wout]           */
+    /* Row-pitched operands (0 = dense rows).  x_pitch: rows of x are x_pitch >= W floats apart and the
+     * x_pitch - W floats behind each row are ZERO (images x_pitch*H*Cin apart); dy_pitch likewise for dy
+     * (rows of Wout).  A 3x3 conv with pad = dil whose taps shift columns by a non-multiple of 4 (dilation
+     * 1, 2) can then copy every shifted 16-byte quad as is - what hangs over a row end reads the zero tail -
+     * instead of falling back to 4-byte copies at the image borders (dcfp_conv2d_pitch_supported tells
+     * whether all three passes of a descriptor take pitched operands; the BatchNorm kernels that produce
+     * x / dy write pitched outputs: dcfp_bn_apply_f32 / dcfp_bn_bwd_apply_f32 `*_pitch`).
+     * fwd reads x pitched, dgrad reads dy pitched, wgrad reads both; outputs are always dense.
+     * Contract for a pitched tensor: besides the zero tails, the (pitch - W) floats in FRONT of its first
+     * element must be readable zeros too (a leading margin of the allocation): the quad that hangs over the
+     * left end of the very first row reads them. */
+    int32_t x_pitch, dy_pitch;
 } DcfpConvDesc;
 
 enum { DCFP_CONV_FWD = 0, DCFP_CONV_DGRAD = 1, DCFP_CONV_WGRAD = 2 };
@@ -83,6 +95,10 @@ typedef struct DcfpWpEntry {
 int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntry* entry);
 int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, int n_entries, int64_t total_blocks,
                                           dcfp_stream_t stream);
+
+/* 1 when forward, dgrad and wgrad of this descriptor all accept the row-pitched operands it names
+ * (x_pitch / dy_pitch > 0): 3x3, stride 1, pad = dil, the 256 x 256 LDS-DMA tiles; else 0. */
+int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d);
 
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
  * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the
@@ -140,11 +156,13 @@ int dcfp_bn_stats_f32(const float* x, int64_t x_nstride, int N, int C, int HW,
                       float* mean, float* var, const DcfpBnRunning* run,
                       void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
 /* y = act( (x-mean)*rsqrt(var+eps)*gamma + beta (+ residual) ), act = ReLU if relu.
- * y_nstride: batch stride of y (0 => dense). */
+ * y_nstride: batch stride of y (0 => dense).  y_pitch != 0 (with W, the row length): the rows of y are
+ * written y_pitch >= W floats apart (DcfpConvDesc.x_pitch of the conv that reads y); the tail behind each
+ * row is the caller's zero padding and is not written. */
 int dcfp_bn_apply_f32(const float* x, const float* mean, const float* var,
                       const float* gamma, const float* beta, float eps,
                       const float* residual, int relu, float* y, int64_t y_nstride,
-                      int N, int C, int HW, dcfp_stream_t stream);
+                      int N, int C, int HW, int W, int y_pitch, dcfp_stream_t stream);
 /* Backward stage 1: with g = dy * mask:
  *   sum_dy[c] = sum g ;  sum_dy_xmu[c] = sum g*(x-mean[c])
  * (dbeta = sum_dy; dgamma = sum_dy_xmu * rsqrt(var+eps): the per-filter statistic
@@ -202,7 +220,8 @@ int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
                           const float* sum_dy, const float* sum_dy_xmu, float count,
                           const float* count_dev,
                           int relu, float* dx, float* d_residual,
-                          int N, int C, int HW, dcfp_stream_t stream);
+                          int N, int C, int HW, int W, int dx_pitch /* as y_pitch above, for dx */,
+                          dcfp_stream_t stream);
 
 /* ------------------------------------------------- element-wise / pooling
  * MaxPool2d(3,2,1) (resnet.py:100,149): -inf padding, first-max index. */

@@ -149,6 +149,84 @@ def test_persistent_1x1_kernel_bit_identical_to_one_tile_kernel(cuda):
     assert any(len(v) == 6 for v in res[0].values())        # the fused-statistics epilogue was exercised
 
 
+@pytest.mark.parametrize("shape", [(3, 256, 64, 256, 256, 2), (2, 256, 128, 256, 512, 1), (4, 320, 96, 128, 264, 2)])
+def test_row_pitched_operands_bit_identical(cuda, shape):
+    """3x3 convs with dilation 1 / 2 reading row-pitched x / dy (zero tail behind each row: DcfpConvDesc.x_pitch,
+    dy_pitch) against the same convs on dense tensors: the un-mixed LDS-DMA kernels copy every shifted quad
+    as is, the dense path handles image borders with 4-byte copies - same products, same order, same bits.
+    Also the BatchNorm kernels that produce the pitched tensors (y_pitch / dx_pitch)."""
+    import torch
+    from dcfp_amd import ops, _lib
+    N, Cin, H, W, Cout, d = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(cuda)
+    dy = torch.randn(N, Cout, H, W, generator=g).to(cuda)
+    pitch = ops.conv_pitch(tuple(x.shape), tuple(w.shape), 1, d, d)
+    assert pitch >= W + d and pitch % 4 == 0
+    desc = ops._desc(x.shape, w.shape, 1, d, d, pitch, pitch)
+    assert [ops.conv_kernel_name(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)] == \
+        ["igemm2_dma_kernel<9,false>", "igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>"]
+    xp = ops.pitched_buffer(tuple(x.shape), pitch, "test_x", cuda); xp.copy_(x)
+    dyp = ops.pitched_buffer(tuple(dy.shape), pitch, "test_dy", cuda); dyp.copy_(dy)
+    assert ops._pitch_of(xp) == pitch and float(xp.as_strided((N, Cin, H, pitch - W), xp.stride(), xp.storage_offset() + W).abs().sum()) == 0.0
+    y0, st0 = ops.conv2d_fwd(x, w, None, 1, d, d, want_stats=True)
+    y1, st1 = ops.conv2d_fwd(xp, w, None, 1, d, d, want_stats=True)
+    assert torch.equal(y0, y1)
+    if st0 is not None:    # the fused BatchNorm statistics group pixels by tile (8 x 32 vs 256 x 1 tiles): same values, other order
+        assert st1 is not None
+        assert (st0[0] - st1[0]).abs().max().item() <= 2e-6 * max(1.0, st0[0].abs().max().item())
+        assert ((st0[1] - st1[1]).abs() / st0[1]).max().item() <= 2e-6
+    assert torch.equal(ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, d, d), ops.conv2d_dgrad(dyp, w, tuple(x.shape), 1, d, d))
+    assert torch.equal(ops.conv2d_wgrad(dy, x, tuple(w.shape), 1, d, d)[0], ops.conv2d_wgrad(dyp, xp, tuple(w.shape), 1, d, d)[0])
+    # producers: BN(+ReLU) forward into a pitched buffer, BN backward dx into a pitched buffer
+    gamma = (torch.rand(Cin, generator=g) + 0.5).to(cuda); beta = (torch.randn(Cin, generator=g) * 0.2).to(cuda)
+    mean, var = ops.bn_stats(x)
+    yd = ops.bn_apply(x, mean, var, gamma, beta, 1e-5, None, True)
+    yp = ops.bn_apply(x, mean, var, gamma, beta, 1e-5, None, True, out=ops.pitched_buffer(tuple(x.shape), pitch, "test_y", cuda))
+    assert torch.equal(yd, yp) and float(yp.as_strided((N, Cin, H, pitch - W), yp.stride(), yp.storage_offset() + W).abs().sum()) == 0.0
+    gin = torch.randn(x.shape, generator=g).to(cuda)
+    s1, s2, _ = ops.bn_bwd_reduce(gin, x, None, mean, var, gamma, beta, 1e-5, 2)
+    cnt = float(N * H * W)
+    dxd, _ = ops.bn_bwd_apply(gin, x, None, mean, var, gamma, beta, 1e-5, s1, s2, cnt, 2, False)
+    dxp, _ = ops.bn_bwd_apply(gin, x, None, mean, var, gamma, beta, 1e-5, s1, s2, cnt, 2, False,
+                              dx_out=ops.pitched_buffer(tuple(x.shape), pitch, "test_dx", cuda))
+    assert torch.equal(dxd, dxp)
+
+
+def test_bottleneck_pitched_path_equals_dense(cuda):
+    """One dilation-2 Bottleneck at a size where conv2 goes row-pitched (256 channels, 4 x 64 x 256 pixels),
+    forward + backward, against the same block with DCFP_PITCHED off (ops.PITCHED): every output and
+    gradient bit for bit; a second forward before the first backward must not clobber the saved y1."""
+    import torch
+    from dcfp_amd import ops
+    from dcfp_amd.networks.backbone.resnet import Bottleneck
+
+    def run(pitched):
+        ops.PITCHED = pitched
+        fuse, ops.FUSE_BN_STATS = ops.FUSE_BN_STATS, False   # (fused statistics group pixels by tile shape: 8 x 32 vs 256 x 1)
+        try:
+            torch.manual_seed(7)
+            blk = Bottleneck(1024, 256, stride=1, dilation=2).to(cuda).train()
+            gx = torch.Generator().manual_seed(8)
+            x = torch.randn(4, 1024, 64, 256, generator=gx).to(cuda).requires_grad_(True)
+            out = blk(x)
+            out2 = blk(x)                      # second graph while the first one is alive
+            gy = torch.randn(out.shape, generator=gx).to(cuda)
+            out.backward(gy)
+            grads = [p.grad.clone() for p in blk.parameters()] + [x.grad.clone()]
+            return out.detach().clone(), out2.detach().clone(), grads, getattr(blk, "_dcfp_pitch", None) is not None
+        finally:
+            ops.PITCHED = True
+            ops.FUSE_BN_STATS = fuse
+    o_p, o2_p, g_p, used = run(True)
+    o_d, o2_d, g_d, _ = run(False)
+    assert used, "conv2 of this block should have taken the row-pitched path"
+    assert torch.equal(o_p, o_d) and torch.equal(o2_p, o2_d)
+    for a, b in zip(g_p, g_d):
+        assert torch.equal(a, b)
+
+
 if __name__ == "__main__" and "--child" in sys.argv:
     _child()
 if __name__ == "__main__" and "--persist-child" in sys.argv:

@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--passes", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="compare all three passes with torch's GPU conv on the full shape")
+    ap.add_argument("--pitched", action="store_true",
+                    help="x / dy row-pitched with a zero tail where the library supports it (ops.conv_pitch)")
     ap.add_argument("--zeros", action="store_true",
                     help="all-zero operands: same instruction stream at much lower switching power")
     args = ap.parse_args()
@@ -68,6 +70,12 @@ def main():
         dy = torch.randn_like(y)
         if args.zeros:
             x.zero_(); w.zero_(); dy.zero_()
+        if args.pitched:
+            pitch = ops.conv_pitch(tuple(x.shape), tuple(w.shape), s, p, d)
+            if pitch:
+                xp = ops.new_pitched(tuple(x.shape), pitch, dev); xp.copy_(x); x = xp
+                dp = ops.new_pitched(tuple(dy.shape), pitch, dev); dp.copy_(dy); dy = dp
+            name = name + ("*" if pitch else "")
         flops = 2.0 * N * Cout * y.shape[2] * y.shape[3] * Cin * k * k
         res = {}
         if "fwd" in args.passes:
