@@ -47,10 +47,28 @@ def _bn_args(m):
     return (m.running_mean, m.running_var, training, momentum, m.eps, sync, nbt)
 
 
-def bn_act(m, x, relu=False, residual=None):
-    """BatchNorm2d / SyncBatchNorm (+ReLU) (+residual add before the ReLU)."""
+def _conv_pitch(cm, xshape):
+    """Row pitch for the shifted operands of conv module `cm` on an input of `xshape` (0: dense)."""
+    if cm is None or cm.kernel_size != (3, 3) or cm.groups != 1 or isinstance(cm.padding, str):
+        return 0
+    return ops.conv_pitch(tuple(xshape), tuple(cm.weight.shape), cm.stride[0], cm.padding[0], cm.dilation[0])
+
+
+def bn_act(m, x, relu=False, residual=None, prev_conv=None, next_conv=None):
+    """BatchNorm2d / SyncBatchNorm (+ReLU) (+residual add before the ReLU).  prev_conv / next_conv: the Conv2d
+    modules that produced x / will read y; where they are dilation-1/2 3x3 convs on the 256 x 256-tile kernels,
+    dx / y are written row-pitched for them (ops.conv_pitch)."""
     rm, rv, training, momentum, eps, sync, nbt = _bn_args(m)
-    return ops.batch_norm_act(x, m.weight, m.bias, rm, rv, residual, relu, training, momentum, eps, sync, nbt)
+    pitch_cfg = None
+    if x.is_cuda and torch.is_grad_enabled() and x.requires_grad and x.dim() == 4:
+        y_pitch = _conv_pitch(next_conv, x.shape) if residual is None else 0
+        dx_pitch = 0
+        if prev_conv is not None and prev_conv.kernel_size == (3, 3):
+            in_shape = (x.shape[0], prev_conv.in_channels, x.shape[2], x.shape[3])    # stride 1, same size if eligible
+            dx_pitch = _conv_pitch(prev_conv, in_shape)
+        if y_pitch or dx_pitch:
+            pitch_cfg = (m, y_pitch, dx_pitch)
+    return ops.batch_norm_act(x, m.weight, m.bias, rm, rv, residual, relu, training, momentum, eps, sync, nbt, pitch_cfg)
 
 
 def _fold(bn):
@@ -70,7 +88,7 @@ def _fold(bn):
     return cached[1], cached[2]
 
 
-def conv_bn_act(cm, bn, x, relu=False, residual=None):
+def conv_bn_act(cm, bn, x, relu=False, residual=None, next_conv=None):
     """conv -> BatchNorm (+residual) (+ReLU).  Inference (BN in eval mode, no autograd): ONE kernel,
     the BN folded into the conv epilogue; otherwise conv + the training BN kernels."""
     if (not bn.training) and bn.running_mean is not None and not torch.is_grad_enabled() \
@@ -78,7 +96,7 @@ def conv_bn_act(cm, bn, x, relu=False, residual=None):
         scale, shift = _fold(bn)
         return ops.conv2d_fused_infer(x, cm.weight, scale, shift, cm.stride[0], cm.padding[0],
                                       cm.dilation[0], residual, relu)
-    return bn_act(bn, conv(cm, x), relu=relu, residual=residual)
+    return bn_act(bn, conv(cm, x), relu=relu, residual=residual, prev_conv=cm, next_conv=next_conv)
 
 
 def _plain_conv(m, k):
@@ -117,7 +135,8 @@ def run_sequential(seq, x):
         m = mods[i]
         if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], _BN_TYPES):
             fuse = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-            x = conv_bn_act(m, mods[i + 1], x, relu=fuse)
+            nxt = mods[i + 3] if fuse and i + 3 < len(mods) else None     # conv -> BN -> ReLU -> conv: y feeds it directly
+            x = conv_bn_act(m, mods[i + 1], x, relu=fuse, next_conv=nxt if isinstance(nxt, nn.Conv2d) else None)
             i += 2 if fuse else 1
         elif isinstance(m, nn.Conv2d):
             x = conv(m, x)

@@ -67,7 +67,7 @@ class Seg_Model(nn.Module):
         """Logits of the head(s) at 1/os resolution (before the bilinear upsample)."""
         _exec.require_device(input)
         x_deepsup, x = self.backbone(input)
-        x = self.aspp(x)
+        x = self.aspp(x, next_conv=self.last_conv[0])     # (the head's first 3x3 conv reads the ASPP output)
         lowres = [_exec.run_sequential(self.last_conv, x)]
         if self.deepsup and deepsup:
             lowres.append(_exec.run_sequential(self.conv_deepsup, x_deepsup))

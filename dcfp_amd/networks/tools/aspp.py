@@ -52,7 +52,7 @@ class ASPP(nn.Module):
                     for m in br) and len(pool) == 4 and isinstance(pool[1], nn.Conv2d) and pool[1].bias is None
                 and pool[1].kernel_size == (1, 1))
 
-    def forward(self, x):
+    def forward(self, x, next_conv=None):
         if _exec.FUSE_BLOCKS and torch.is_grad_enabled() and x.requires_grad and self._fused_ok():
             # training: branches + concat as one autograd node writing channel slices (no torch.cat, input
             # gradients accumulated by the dgrad epilogue)
@@ -72,5 +72,5 @@ class ASPP(nn.Module):
             x5 = ops.broadcast_to_hw(x5, x4.shape[2], x4.shape[3])
             x = torch.cat((x1, x2, x3, x4, x5), dim=1)
         if self.outplanes is not None:
-            x = _exec.conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            x = _exec.conv_bn_act(self.conv1, self.bn1, x, relu=True, next_conv=next_conv)
         return x

@@ -119,6 +119,26 @@ def pitched_buffer(shape, pitch, key, device):
     return buf
 
 
+def owner_pitched(owner, shape, pitch, device, track=True):
+    """The persistent row-pitched buffer of a module's output (it lives from the forward to the backward of the
+    conv that reads it): (view, slot).  slot["busy"] is set while a graph holds the buffer - a second forward
+    before that graph's backward gets a fresh buffer instead (slot None)."""
+    slot = getattr(owner, "_dcfp_pitch", None) if owner is not None else None
+    if slot is not None and not slot["busy"] and tuple(slot["y"].shape) == tuple(shape) and _pitch_of(slot["y"]) == pitch \
+            and slot["y"].device == device:
+        view = slot["y"]
+    else:
+        view = new_pitched(shape, pitch, device)
+        if owner is not None and (slot is None or not slot["busy"]):
+            slot = {"y": view, "busy": False}
+            owner._dcfp_pitch = slot
+        else:
+            slot = None
+    if slot is not None and track:
+        slot["busy"] = True
+    return view, (slot if track else None)
+
+
 def new_pitched(shape, pitch, device):
     """Fresh zeroed row-pitched [N,C,H,W] view.  The allocation starts with a margin of zeros (the contract of
     DcfpConvDesc.x_pitch: the pitch - W floats in front of the first element are readable zeros)."""
@@ -693,10 +713,18 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, training,
-                momentum, eps, sync, nbt):
+                momentum, eps, sync, nbt, pitch_cfg):
         x = x.contiguous()
+        # pitch_cfg = (owner module, y_pitch, dx_pitch): write y row-pitched for the 3x3 conv that reads it next /
+        # write dx row-pitched for the 3x3 conv that produced x (their shifted operands: conv_pitch)
+        out, ctx.pitch_slot, ctx.dx_pitch = None, None, 0
+        if pitch_cfg is not None:
+            owner, y_pitch, ctx.dx_pitch = pitch_cfg
+            if y_pitch and residual is None:
+                out, ctx.pitch_slot = owner_pitched(owner, tuple(x.shape), y_pitch, x.device,
+                                                    track=torch.is_grad_enabled())
         y, state = bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu,
-                                   training, momentum, eps, sync, nbt=nbt)
+                                   training, momentum, eps, sync, nbt=nbt, out=out)
         mean, var, count, group = state[:4]
         # y is saved only where the ReLU mask cannot be re-derived from x (residual input)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var,
@@ -713,8 +741,12 @@ class BatchNormActFn(torch.autograd.Function):
         relu, training, eps, count, group, has_res = ctx.cfg
         state = (mean, var, count_t if count_t is not None else count, group)
         need_res = has_res and ctx.needs_input_grad[5]
-        dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, need_res)
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        dx_out = pitched_buffer(tuple(x.shape), ctx.dx_pitch, "bn_dx", x.device) if ctx.dx_pitch else None
+        dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, need_res,
+                                                   dx_out=dx_out)
+        if ctx.pitch_slot is not None:
+            ctx.pitch_slot["busy"] = False
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 class BottleneckFn(torch.autograd.Function):
@@ -758,24 +790,9 @@ class BottleneckFn(torch.autograd.Function):
         N_, _, H_, W_ = x.shape
         y1_shape = (N_, w1.shape[0], H_, W_)
         pitch = conv_pitch(y1_shape, tuple(w2.shape), stride, dil, dil)
-        y1_out, owner = None, cfg.get("owner")
+        y1_out, ctx.pitch_slot = None, None
         if pitch:
-            slot = getattr(owner, "_dcfp_pitch", None) if owner is not None else None
-            if slot is not None and not slot["busy"] and tuple(slot["y1"].shape) == y1_shape and _pitch_of(slot["y1"]) == pitch \
-                    and slot["y1"].device == x.device:
-                y1_out = slot["y1"]
-            else:
-                y1_out = new_pitched(y1_shape, pitch, x.device)
-                if owner is not None and (slot is None or not slot["busy"]):
-                    slot = {"y1": y1_out, "busy": False}
-                    owner._dcfp_pitch = slot
-                else:
-                    slot = None
-            if slot is not None:
-                slot["busy"] = True
-            ctx.pitch_slot = slot
-        else:
-            ctx.pitch_slot = None
+            y1_out, ctx.pitch_slot = owner_pitched(cfg.get("owner"), y1_shape, pitch, x.device)
         ctx.pitch = pitch
         c1, y1, st1 = conv_bn(x, w1, bnargs[0], g1, b1, out=y1_out)
         c2, y2, st2 = conv_bn(y1, w2, bnargs[1], g2, b2, stride, dil, dil)
@@ -865,9 +882,9 @@ def bottleneck(x, cfg, tensors):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
-                   training=True, momentum=0.1, eps=1e-5, sync=False, nbt=None):
+                   training=True, momentum=0.1, eps=1e-5, sync=False, nbt=None, pitch_cfg=None):
     return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, relu,
-                                training, momentum, eps, sync, nbt)
+                                training, momentum, eps, sync, nbt, pitch_cfg)
 
 
 class AsppFn(torch.autograd.Function):
