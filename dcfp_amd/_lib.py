@@ -43,7 +43,7 @@ class BnRunning(C.Structure):
 class WpEntry(C.Structure):
     """DcfpWpEntry: one weight tensor -> permuted copy of the multi-tensor refresh."""
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("first_block", C.c_int64), ("n_blocks", C.c_int64)] + \
-               [(n, C.c_int32) for n in ("T", "Ck", "CkP", "M", "Mpad", "sAm", "sAc", "pad_")]
+               [(n, C.c_int32) for n in ("T", "Ck", "CkP", "M", "Mpad", "sAm", "sAc", "perm8")]
 
 
 SGD_CHUNK = 16384

@@ -56,7 +56,10 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 bool dcfp_igemm2_persist();
-void dcfp_igemm2_wp_layout(int T, int M, int Ck, long long px, int sd, int sAm, int sAc, DcfpWpEntry* e);
+void dcfp_igemm2_wp_layout(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
+                           int Wo, bool pitched, int sAm, int sAc, DcfpWpEntry* e);
+bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
+                          int Wo, bool pitched);
 int dcfp_igemm2_permute_multi(const DcfpWpEntry* table, int n, long long total_blocks, hipStream_t stream);
 
 
@@ -107,6 +110,14 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     const int P = pass == DCFP_CONV_FWD ? d->Hout * d->Wout : d->H * d->W;
     const int HiWi = pass == DCFP_CONV_FWD ? d->H * d->W : d->Hout * d->Wout;
     const int Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
+    {
+        const int sp = pass == DCFP_CONV_FWD ? d->x_pitch : d->dy_pitch;
+        const bool pitched = sp && sp != (pass == DCFP_CONV_FWD ? d->W : d->Wout);
+        if (dcfp_igemm2_use_dma8(d->KH * d->KW, M, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd,
+                                 pass == DCFP_CONV_FWD ? -d->pad : d->pad, pass == DCFP_CONV_FWD ? d->dil : -d->dil,
+                                 HiWi, pass == DCFP_CONV_FWD ? d->Wout : d->W, pitched))
+            return snprintf(buf, buf_len, "igemm2_dma8_kernel<%d>", d->KH * d->KW);
+    }
     if (dcfp_igemm2_dma_shape(d->KH * d->KW, M, Ck, P, px, pass == DCFP_CONV_FWD ? d->stride : 1, sd, d->pad, HiWi,
                               pass == DCFP_CONV_FWD ? d->Wout : d->W)) {
         if (d->KH == 1 && dcfp_igemm2_persist()) return snprintf(buf, buf_len, "igemm2_dma1p_kernel");   // <ACC>
@@ -217,11 +228,13 @@ extern "C" int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntr
     if (pass == DCFP_CONV_FWD) {
         const long long px = (long long)d->N * d->Hout * d->Wout;
         if (igemm3_ok(d->Cout, px, d->stride, 1)) return DCFP_E_UNSUPPORTED;     // bf16x3 keeps its own split copy
-        dcfp_igemm2_wp_layout(T, d->Cout, d->Cin, px, 1, d->Cin * T, T, e);
+        dcfp_igemm2_wp_layout(T, d->Cout, d->Cin, d->Hout * d->Wout, px, d->stride, 1, -d->pad, d->dil, d->H * d->W,
+                              d->Wout, d->x_pitch && d->x_pitch != d->W, d->Cin * T, T, e);
     } else {
         const long long px = (long long)d->N * d->H * d->W;
         if (igemm3_ok(d->Cin, px, 1, d->stride)) return DCFP_E_UNSUPPORTED;
-        dcfp_igemm2_wp_layout(T, d->Cin, d->Cout, px, d->stride, T, d->Cin * T, e);
+        dcfp_igemm2_wp_layout(T, d->Cin, d->Cout, d->H * d->W, px, 1, d->stride, d->pad, -d->dil, d->Hout * d->Wout,
+                              d->W, d->dy_pitch && d->dy_pitch != d->Wout, T, d->Cin * T, e);
     }
     const long long total = (long long)e->T * e->CkP * e->Mpad;
     e->n_blocks = (total + DCFP_WP_BLOCK_ELEMS - 1) / DCFP_WP_BLOCK_ELEMS;

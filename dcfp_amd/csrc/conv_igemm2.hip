@@ -18,14 +18,21 @@
 
 namespace {
 
+// perm8 (conv_igemm2n.hip): inside every 256-row tile, position 8 l + i holds channel 32 i + l
+__device__ __forceinline__ int wp_row(int m, int perm8) {
+    if (!perm8) return m;
+    const int j = m & 255;
+    return (m & ~255) + 32 * (j & 7) + (j >> 3);
+}
+
 // Wp[t][c][m] = W[m*sAm + c*sAc + t]  (zero for c >= Ck or m >= M)
 __global__ void __launch_bounds__(256)
 permute_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int T, int Ck, int CkP,
-                       int M, int Mpad, int sAm, int sAc) {
+                       int M, int Mpad, int sAm, int sAc, int perm8) {
     const long long total = (long long)T * CkP * Mpad;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
          i += (long long)gridDim.x * 256) {
-        const int m = (int)(i % Mpad);
+        const int m = wp_row((int)(i % Mpad), perm8);
         const long long r = i / Mpad;
         const int c = (int)(r % CkP);
         const int t = (int)(r / CkP);
@@ -53,7 +60,7 @@ permute_weights_multi_kernel(const DcfpWpEntry* __restrict__ table, int n) {
     for (int u = 0; u < kWpBlockElems / 256; ++u) {
         const long long i = base + u * 256 + threadIdx.x;
         if (i >= total) return;
-        const int m = (int)(i % e.Mpad);
+        const int m = wp_row((int)(i % e.Mpad), e.perm8);
         const long long r = i / e.Mpad;
         const int c = (int)(r % e.CkP);
         const int t = (int)(r / e.CkP);
@@ -915,14 +922,17 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+// implemented in conv_igemm2n.hip: 8 x 2 wave tiles with dead row blocks skipped (ragged M)
+int dcfp_igemm2n_launch(const Igemm2Params& p, int T, hipStream_t stream);
+
 // implemented in conv_igemm2p.hip: the persistent 1x1 LDS-DMA kernel
 int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream);
 bool dcfp_igemm2_persist();
 
 // ---- entry points used by conv_igemm.hip's C-ABI functions
 size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd) {
-    const TileCfg c = pick_cfg(M, px, sd);
-    return (size_t)T * round_up(Ck, ck_pad()) * round_up(M, c.bm) * sizeof(float);
+    // rows rounded to 256: covers every tile height and the permuted 256-row layout of conv_igemm2n.hip
+    return (size_t)T * round_up(Ck, ck_pad()) * round_up(M, 256) * sizeof(float);
 }
 
 int dcfp_igemm2_cfg_id(int M, long long px, int sd) { return pick_cfg(M, px, sd).id; }
@@ -947,11 +957,30 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
     }
 }
 
-// Layout of the Wp copy dcfp_igemm2_run would build for this problem (everything but the pointers)
-void dcfp_igemm2_wp_layout(int T, int M, int Ck, long long px, int sd, int sAm, int sAc, DcfpWpEntry* e) {
+// Ragged output-channel counts on the 8 x 2 kernel of conv_igemm2n.hip: same shape conditions as the other
+// LDS-DMA kernels (shifted quads must not need border handling: column shifts multiples of 4, or a row-pitched
+// source), enough pixel tiles to fill the chip, and >= 20 % less MFMA work than the tile the shape gets otherwise.
+// DCFP_IGEMM_DMA8=0: off.
+bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
+                          int Wo, bool pitched) {
+    static const bool on = [] { const char* e = getenv("DCFP_IGEMM_DMA8"); return !e || atoi(e) != 0; }();
+    static const bool dma = [] { const char* e = getenv("DCFP_IGEMM_DMA"); return !e || atoi(e) != 0; }();
+    if (!on || !dma || deep_k() || sn != 1 || sd != 1 || HiWi != P || Wo % 4 != 0) return false;
+    if (T == 1 ? off0 != 0 : ((((off0 | offstep) & 3) != 0 && !pitched) || off0 + 2 * offstep != -off0)) return false;
+    const long long tiles = ((long long)P + 255) / 256 * (px / P) * ((M + 255) / 256);
+    if (tiles < 192) return false;
     const TileCfg c = pick_cfg(M, px, sd);
-    e->T = T; e->Ck = Ck; e->CkP = round_up(Ck, ck_pad()); e->M = M; e->Mpad = round_up(M, c.bm);
-    e->sAm = sAm; e->sAc = sAc;
+    const long long old_rows = (long long)((M + c.bm - 1) / c.bm) * c.bm, new_rows = (long long)((M + 31) / 32) * 32;
+    return 10 * old_rows >= 12 * new_rows;
+}
+
+// Layout of the Wp copy dcfp_igemm2_run would build for this problem (everything but the pointers)
+void dcfp_igemm2_wp_layout(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
+                           int Wo, bool pitched, int sAm, int sAc, DcfpWpEntry* e) {
+    const TileCfg c = pick_cfg(M, px, sd);
+    const bool d8 = dcfp_igemm2_use_dma8(T, M, P, px, sn, sd, off0, offstep, HiWi, Wo, pitched);
+    e->T = T; e->Ck = Ck; e->CkP = round_up(Ck, ck_pad()); e->M = M; e->Mpad = round_up(M, d8 ? 256 : c.bm);
+    e->sAm = sAm; e->sAc = sAc; e->perm8 = d8 ? 1 : 0;
 }
 
 int dcfp_igemm2_permute_multi(const DcfpWpEntry* table, int n, long long total_blocks, hipStream_t stream) {
@@ -988,6 +1017,10 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
+    const bool plain = !bias && !scale && !relu && !stat_part;
+    const bool d8 = plain && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo,
+                                                  in_pitch > 0 && in_pitch != Wi);
+    if (d8) p.Mpad = round_up(M, 256);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
     p.in_pitch = in_pitch > 0 ? in_pitch : Wi;
     const bool pitched = p.in_pitch != Wi;
@@ -1002,7 +1035,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         const bool fits = (t2d == 4 || t2d == 5) && Hi % (256 >> t2d) == 0 && Wi % (1 << t2d) == 0;
         p.tile2d = (fits && !pitched && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
     }
-    p.tiles_per_img = (p.P + c.bn - 1) / c.bn;
+    p.tiles_per_img = (p.P + (d8 ? 256 : c.bn) - 1) / (d8 ? 256 : c.bn);
     p.Hc = p.Wc = p.tiles_per_phase = p.zfold = 0;
     if (sd > 1) {     // strided dgrad: sd*sd phases, each tiled over its own coarse grid
         p.Hc = (Ho + sd - 1) / sd; p.Wc = (Wo + sd - 1) / sd;
@@ -1015,7 +1048,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         }
     }
     p.tiles_n_total = p.tiles_per_img * N;
-    p.tiles_m = p.Mpad / c.bm;
+    p.tiles_m = p.Mpad / (d8 ? 256 : c.bm);
     p.sn = sn; p.sd = sd; p.off0 = off0; p.offstep = offstep;
     p.accumulate = accumulate;
     p.vec_store = (p.P % 4 == 0) && (out_nstride % 4 == 0) && dcfp_aligned16(out);
@@ -1028,7 +1061,11 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         long long b = (total + 255) / 256;
         if (b > 2048) b = 2048;
         hipLaunchKernelGGL(permute_weights_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, wp, T,
-                           Ck, p.CkP, M, p.Mpad, sAm, sAc);
+                           Ck, p.CkP, M, p.Mpad, sAm, sAc, d8 ? 1 : 0);
+    }
+    if (d8) {
+        if (!p.vec_store) return DCFP_E_UNSUPPORTED;
+        return dcfp_igemm2n_launch(p, T, stream);
     }
     if (dcfp_igemm2_dma_shape(T, M, Ck, p.P, px, sn, sd, off0, Hi * Wi, Wo) && p.vec_store && !bias && !scale &&
         !relu && !(stat_part && accumulate)) {

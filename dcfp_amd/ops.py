@@ -193,14 +193,16 @@ _WP_OWNERS = weakref.WeakSet()     # weight tensors that carry permuted copies (
 _WP_TABLE = {"version": 0, "built": -1, "dev": None, "n": 0, "blocks": 0, "entries": []}
 
 
-def _wp_buffer(w, which, d, nbytes):
+def _wp_buffer(w, which, d, nbytes, variant=""):
     """Persistent buffer for the permuted weight copy Wp of (weight tensor, pass, shape) and whether the
     library may skip rebuilding it (`wp_valid` of include/dcfp_hip.h).  Validity = same storage, same torch
     version counter and same WEIGHT_EPOCH (raw-pointer writes by FusedSGD).  In training every weight changes
     once per step: FusedSGD.step() then calls refresh_wp(), ONE multi-tensor launch that rebuilds every
     registered copy (forward and dgrad layouts of all convs) and re-validates them, instead of a permute
     launch inside each of the 233 conv calls of a step."""
-    key = (which, d.N, d.H, d.W, d.stride, d.pad, d.dil)
+    # (the copy's layout depends on the kernel the shape routes to, which depends on the operand pitches and,
+    # for the inference call with its fused epilogue, on the variant: separate entries)
+    key = (which, d.N, d.H, d.W, d.stride, d.pad, d.dil, d.x_pitch, d.dy_pitch, variant)
     tag = (w.data_ptr(), w._version, WEIGHT_EPOCH[0], torch.cuda.current_stream().cuda_stream)
     cache = getattr(w, "_dcfp_wp", None)
     if cache is None:
@@ -237,6 +239,8 @@ def refresh_wp():
             if not w.is_cuda or not w.is_contiguous():
                 continue
             for key, (tag, buf, desc) in list(w._dcfp_wp.items()):
+                if key[-1]:          # inference-variant copies rebuild on demand (their layout is the call's own)
+                    continue
                 e = _lib.WpEntry()
                 if L.dcfp_conv2d_wp_layout(C.byref(desc), key[0], C.byref(e)) != 0:
                     continue
@@ -1301,7 +1305,7 @@ def conv2d_fused_infer(x, w, scale, shift, stride=1, pad=0, dil=1, residual=None
         if tuple(residual.shape) != tuple(y.shape):
             raise RuntimeError("conv2d_fused_infer: residual shape mismatch")
     L = _lib.lib()
-    ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD))
+    ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), "fused")
     check(L.dcfp_conv2d_fwd_fused_f32_nchw(C.byref(d), _p(x), _p(w), _p(scale.contiguous()),
                                            _p(shift.contiguous()), _p(residual), int(bool(relu)), _p(y),
                                            _p(ws), ws.numel(), valid, _stream()), "conv2d_fwd_fused")

@@ -90,7 +90,8 @@ typedef struct DcfpWpEntry {
     float* wp;
     int64_t first_block;
     int64_t n_blocks;
-    int32_t T, Ck, CkP, M, Mpad, sAm, sAc, pad_;
+    int32_t T, Ck, CkP, M, Mpad, sAm, sAc;
+    int32_t perm8;   /* rows of every 256-row tile permuted for the ragged-M kernel (position 8l+i <- channel 32i+l) */
 } DcfpWpEntry;
 int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntry* entry);
 int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, int n_entries, int64_t total_blocks,

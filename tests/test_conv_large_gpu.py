@@ -194,6 +194,65 @@ def test_row_pitched_operands_bit_identical(cuda, shape):
     assert torch.equal(dxd, dxp)
 
 
+RAGGED = [
+    # N, Cin, H, W, Cout, k, pad, dil, pitched, (fwd kernel, dgrad kernel)
+    ((4, 256, 128, 256, 154, 1, 0, 1, False), ("igemm2_dma8_kernel<1>", None)),            # pruned 1x1: 5 of 8 row blocks live
+    ((2, 256, 128, 256, 154, 3, 4, 4, False), ("igemm2_dma8_kernel<9>", None)),            # 3x3, column shifts multiples of 4
+    ((2, 83, 128, 256, 256, 3, 12, 12, False), (None, "igemm2_dma8_kernel<9>")),           # dgrad with M = Cin = 83
+    ((3, 256, 64, 256, 150, 3, 2, 2, True), ("igemm2_dma8_kernel<9>", None)),              # dilation 2 on a row-pitched source
+    ((2, 128, 128, 256, 300, 1, 0, 1, False), ("igemm2_dma8_kernel<1>", None)),            # two M tiles: 8 + 2 live row blocks
+    ((4, 2048, 96, 128, 40, 3, 12, 12, False), ("igemm2_dma8_kernel<9>", None)),           # pruned ASPP branch: M = 40, long K
+]
+
+
+@pytest.mark.parametrize("case,kernels", RAGGED)
+def test_ragged_m_kernel(cuda, case, kernels):
+    """conv_igemm2n.hip (8 x 2 wave tiles, dead row blocks skipped, permuted weight rows) on pruned widths:
+    forward / dgrad / accumulate-dgrad against fp64 on channel slices, routing asserted."""
+    import torch
+    import torch.nn.functional as F
+    from dcfp_amd import ops, _lib
+    N, Cin, H, W, Cout, k, p, d, pitched = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = (torch.relu(x) + 0.05 * x).to(cuda)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).to(cuda)
+    dy = (torch.randn(N, Cout, H, W, generator=g) * 1e-2).to(cuda)
+    xin, dyin, pitch = x, dy, 0
+    if pitched:
+        pitch = ops.conv_pitch(tuple(x.shape), tuple(w.shape), 1, p, d)
+        assert pitch
+        xin = ops.new_pitched(tuple(x.shape), pitch, cuda); xin.copy_(x)
+        dyin = ops.new_pitched(tuple(dy.shape), pitch, cuda); dyin.copy_(dy)
+    desc = ops._desc(x.shape, w.shape, 1, p, d, pitch, pitch)
+    for want, which in zip(kernels, (_lib.CONV_FWD, _lib.CONV_DGRAD)):
+        if want is not None:
+            assert ops.conv_kernel_name(desc, which) == want, ops.conv_kernel_name(desc, which)
+    y = ops.conv2d_fwd(xin, w, None, 1, p, d)
+    y_again = ops.conv2d_fwd(xin, w, None, 1, p, d)              # second call: cached (permuted) Wp, wp_valid = 1
+    assert torch.equal(y, y_again)
+    dx = ops.conv2d_dgrad(dyin, w, tuple(x.shape), 1, p, d)
+    seed = torch.randn(x.shape, generator=g).to(cuda)
+    dxa = seed.clone()
+    ops.conv2d_dgrad(dyin, w, tuple(x.shape), 1, p, d, out=dxa, accumulate=True)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return ((a.double() - b).norm() / b.norm()).item()
+    mo = slice(max(0, Cout - 40), Cout)                             # the ragged last row blocks
+    y64 = F.conv2d(x.double(), w[mo].double(), None, 1, p, d)
+    ci = slice(max(0, Cin - 24), Cin)
+    x64 = x[:, ci].double().requires_grad_(True)
+    F.conv2d(x64, w[:, ci].double(), None, 1, p, d).backward(dy.double())
+    K = Cin * k * k
+    tol = 3e-6 * max(1.0, math.sqrt(K) / 8)
+    assert rel(y[:, mo], y64) < tol, rel(y[:, mo], y64)
+    y64b = F.conv2d(x.double(), w[:8].double(), None, 1, p, d)      # first row block too
+    assert rel(y[:, :8], y64b) < tol
+    assert rel(dx[:, ci], x64.grad) < max(tol, 1e-5), rel(dx[:, ci], x64.grad)
+    assert rel(dxa[:, ci], x64.grad + seed[:, ci].double()) < max(tol, 1e-5)
+
+
 def test_bottleneck_pitched_path_equals_dense(cuda):
     """One dilation-2 Bottleneck at a size where conv2 goes row-pitched (256 channels, 4 x 64 x 256 pixels),
     forward + backward, against the same block with DCFP_PITCHED off (ops.PITCHED): every output and
