@@ -294,21 +294,36 @@ __global__ void syncbn_combine_kernel(const float* __restrict__ allv, int world,
 // Work split (round 2: the one-block-per-channel version read 8 bytes at a stride of C*8 - one 64-byte line per
 // load - and took 13.8 us per BatchNorm): a block owns 32 consecutive channels; thread (g = t / 32, l = t % 32)
 // sums the slots s = g, g + 8, ... of channel c0 + l, so a wave's loads cover 2 x 256 contiguous bytes, and the 8
-// partial sums of a channel are added in the fixed order g = 0..7 (deterministic).
-constexpr int kSfpCh = 32, kSfpGroups = kThreads / kSfpCh;
-__global__ void __launch_bounds__(kThreads)
+// partial sums of a channel are added in a fixed order (deterministic).
+constexpr int kSfpThreads = 1024;
+// (1024 threads: a channel's slots are spread over 32 threads, each keeping 4 loads in flight - with 8 threads per
+// channel and one load at a time the kernel was latency-bound at ~70 us)
+// kSfpCh channels per block (8 for narrow layers with many slots - the 64-channel stem has 16 384 - else 32)
+template <int kSfpCh>
+__global__ void __launch_bounds__(kSfpThreads)
 bn_stats_from_partials_kernel(const float* __restrict__ part, long long S, int cnt, int C,
                               float* __restrict__ mean, float* __restrict__ var, DcfpBnRunning run) {
+    constexpr int kSfpGroups = kSfpThreads / kSfpCh;
     __shared__ double red[kSfpGroups][kSfpCh];
     __shared__ double mu_s[kSfpCh];
     const int l = threadIdx.x % kSfpCh, g = threadIdx.x / kSfpCh;
     const int c = blockIdx.x * kSfpCh + l;
     const bool on = c < C;
     const float2* p2 = reinterpret_cast<const float2*>(part);
-    double a = 0.0;
-    if (on)
-        for (long long s = g; s < S; s += kSfpGroups) a += (double)p2[s * C + c].x;
-    red[g][l] = a;
+    constexpr int U = 4;
+    double a[U] = {0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        long long s = g;
+        for (; s + (U - 1) * kSfpGroups < S; s += U * kSfpGroups) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = p2[(s + u * kSfpGroups) * C + c].x;
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] += (double)v[u];
+        }
+        for (; s < S; s += kSfpGroups) a[0] += (double)p2[s * C + c].x;
+    }
+    red[g][l] = (a[0] + a[1]) + (a[2] + a[3]);
     __syncthreads();
     if (g == 0) {
         double t = 0.0;
@@ -318,15 +333,27 @@ bn_stats_from_partials_kernel(const float* __restrict__ part, long long S, int c
     }
     __syncthreads();
     const double mu = mu_s[l];
-    double b = 0.0;
-    if (on)
-        for (long long s = g; s < S; s += kSfpGroups) {
+    double b[U] = {0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        long long s = g;
+        for (; s + (U - 1) * kSfpGroups < S; s += U * kSfpGroups) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = p2[(s + u * kSfpGroups) * C + c];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double d = (double)v[u].x - mu;
+                b[u] += (double)v[u].y + (double)cnt * d * d;
+            }
+        }
+        for (; s < S; s += kSfpGroups) {
             const float2 v = p2[s * C + c];
             const double d = (double)v.x - mu;
-            b += (double)v.y + (double)cnt * d * d;
+            b[0] += (double)v.y + (double)cnt * d * d;
         }
+    }
     __syncthreads();
-    red[g][l] = b;
+    red[g][l] = (b[0] + b[1]) + (b[2] + b[3]);
     __syncthreads();
     if (g == 0 && on) {
         double t = 0.0;
@@ -608,7 +635,11 @@ extern "C" int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t sl
     DcfpBnRunning rn;
     if (run_arg(run, &rn)) return DCFP_E_BADDESC;
     if (reinterpret_cast<uintptr_t>(partials) & 7u) return DCFP_E_BADDESC;
-    hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((unsigned)((C + kSfpCh - 1) / kSfpCh)), dim3(kThreads), 0,
-                       dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
+    if (C <= 128)
+        hipLaunchKernelGGL(bn_stats_from_partials_kernel<8>, dim3((unsigned)((C + 7) / 8)), dim3(kSfpThreads), 0,
+                           dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
+    else
+        hipLaunchKernelGGL(bn_stats_from_partials_kernel<32>, dim3((unsigned)((C + 31) / 32)), dim3(kSfpThreads), 0,
+                           dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
     DCFP_RETURN_LAUNCH();
 }

@@ -257,7 +257,12 @@ extern "C" int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d) {
     if (xp < d->W + d->pad && xp != d->W) return 0;
     if (dp < d->Wout + d->pad && dp != d->Wout) return 0;
     const long long pxo = (long long)d->N * d->Hout * d->Wout, pxi = (long long)d->N * d->H * d->W;
-    if (!dcfp_igemm2_dma_shape(9, d->Cout, d->Cin, d->Hout * d->Wout, pxo, 1, 1, -d->pad, d->H * d->W, d->Wout)) return 0;
-    if (!dcfp_igemm2_dma_shape(9, d->Cin, d->Cout, d->H * d->W, pxi, 1, 1, d->pad, d->Hout * d->Wout, d->W)) return 0;
+    // each of forward / dgrad on the 256 x 256 LDS-DMA kernel or on the ragged-M one (conv_igemm2n.hip)
+    if (!dcfp_igemm2_dma_shape(9, d->Cout, d->Cin, d->Hout * d->Wout, pxo, 1, 1, -d->pad, d->H * d->W, d->Wout) &&
+        !dcfp_igemm2_use_dma8(9, d->Cout, d->Hout * d->Wout, pxo, 1, 1, -d->pad, d->dil, d->H * d->W, d->Wout, true))
+        return 0;
+    if (!dcfp_igemm2_dma_shape(9, d->Cin, d->Cout, d->H * d->W, pxi, 1, 1, d->pad, d->Hout * d->Wout, d->W) &&
+        !dcfp_igemm2_use_dma8(9, d->Cin, d->H * d->W, pxi, 1, 1, d->pad, -d->dil, d->Hout * d->Wout, d->W, true))
+        return 0;
     return dcfp_wgrad_pitch_ok(d) ? 1 : 0;
 }

@@ -963,15 +963,23 @@ const char* dcfp_igemm2_cfg_args(int M, long long px, int sd) {
 // DCFP_IGEMM_DMA8=0: off.
 bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
                           int Wo, bool pitched) {
-    static const bool on = [] { const char* e = getenv("DCFP_IGEMM_DMA8"); return !e || atoi(e) != 0; }();
+    static const int mode = [] { const char* e = getenv("DCFP_IGEMM_DMA8"); return e ? atoi(e) : 1; }();   // 0 off, 2 = wherever eligible (A/B)
     static const bool dma = [] { const char* e = getenv("DCFP_IGEMM_DMA"); return !e || atoi(e) != 0; }();
+    const bool on = mode != 0;
     if (!on || !dma || deep_k() || sn != 1 || sd != 1 || HiWi != P || Wo % 4 != 0) return false;
     if (T == 1 ? off0 != 0 : ((((off0 | offstep) & 3) != 0 && !pitched) || off0 + 2 * offstep != -off0)) return false;
     const long long tiles = ((long long)P + 255) / 256 * (px / P) * ((M + 255) / 256);
     if (tiles < 192) return false;
+    if (mode == 2) return true;
+    // Measured (tools/conv_bench.py, profiles/r02_dma8_ab.txt): at 8 live row blocks this kernel is 10..17 % slower
+    // than the 4 x 4-tile kernels (8-byte stores, 2-way LDS conflicts on the A fragments, no fused BatchNorm
+    // statistics), at 7 of 8 it is 10 % faster, and on ragged M <= 64 it beats the register-staged 64 x 512
+    // tile by 32..35 % at the same MFMA count.
     const TileCfg c = pick_cfg(M, px, sd);
+    if (M % c.bm == 0) return false;           // exact fit: the tile kernels (and their statistics epilogue) stay
+    if (c.bm <= 64) return true;
     const long long old_rows = (long long)((M + c.bm - 1) / c.bm) * c.bm, new_rows = (long long)((M + 31) / 32) * 32;
-    return 10 * old_rows >= 12 * new_rows;
+    return 10 * new_rows <= 9 * old_rows;
 }
 
 // Layout of the Wp copy dcfp_igemm2_run would build for this problem (everything but the pointers)
@@ -1017,18 +1025,20 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
-    const bool plain = !bias && !scale && !relu && !stat_part;
+    const bool plain = !scale && !relu && !stat_part;     // (bias is handled by the ragged-M kernel's epilogue)
     const bool d8 = plain && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo,
                                                   in_pitch > 0 && in_pitch != Wi);
     if (d8) p.Mpad = round_up(M, 256);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
     p.in_pitch = in_pitch > 0 ? in_pitch : Wi;
     const bool pitched = p.in_pitch != Wi;
-    if (pitched) {   // only the 9-tap LDS-DMA kernel reads pitched sources; every tap's column shift must fit the tail
+    if (pitched) {   // only the 9-tap LDS-DMA kernels read pitched sources; every tap's column shift must fit the tail
         const int reach = off0 < 0 ? -off0 : off0;      // |first tap shift|; the last is off0 + 2*offstep = -off0 (pad = dil)
         if (T != 9 || p.in_pitch < Wi + reach || off0 + 2 * offstep != -off0 || (p.in_pitch & 3) ||
-            !dcfp_igemm2_dma_shape(T, M, Ck, Ho * Wo, px, sn, sd, off0, Hi * Wi, Wo) || bias || scale || relu)
+            (!d8 && (bias || !dcfp_igemm2_dma_shape(T, M, Ck, Ho * Wo, px, sn, sd, off0, Hi * Wi, Wo))) || scale || relu)
             return DCFP_E_UNSUPPORTED;
+        if (!d8 && stat_part && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo, true))
+            return DCFP_E_UNSUPPORTED;                  // (cannot happen: such shapes report no statistics slots)
     }
     {
         static const int t2d = [] { const char* e = getenv("DCFP_IGEMM_2D"); return e ? atoi(e) : 5; }();   // 0: off; 4 / 5: 16 / 32 columns

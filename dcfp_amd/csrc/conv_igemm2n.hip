@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256) igemm2_dma8_kernel(const Igemm2Params p) 
                     if (m < p.M) {
                         float* dst = o_img + (long long)m * p.P + pix;
                         f32x2 v = {acc[i][0][r], acc[i][1][r]};
+                        if (p.bias) { const float bsv = p.bias[m]; v[0] += bsv; v[1] += bsv; }
                         if constexpr (ACC) v += *reinterpret_cast<const f32x2*>(dst);
                         *reinterpret_cast<f32x2*>(dst) = v;
                     }

@@ -35,6 +35,14 @@ SHAPES = {
     "p_l3c1_1x1": (4, 1024, 128, 256, 236, 1, 1, 0, 1),
     "p_l3c2_3x3d2": (4, 236, 128, 256, 232, 3, 1, 2, 2),
     "p_l3c3_1x1": (4, 232, 128, 256, 1024, 1, 1, 0, 1),
+    "p_l3c2b": (4, 204, 128, 256, 188, 3, 1, 2, 2),
+    "p_l3c2c": (4, 169, 128, 256, 147, 3, 1, 2, 2),
+    "p_last0": (4, 512, 128, 256, 154, 3, 1, 1, 1),
+    "p_aspp83": (4, 2048, 128, 256, 83, 3, 1, 36, 36),
+    "p_aspp57": (4, 2048, 128, 256, 57, 3, 1, 24, 24),
+    "p_aspp40": (4, 2048, 128, 256, 40, 3, 1, 12, 12),
+    "p_stem": (4, 62, 512, 1024, 118, 3, 1, 1, 1),
+    "p_l3c1b": (4, 1024, 128, 256, 210, 1, 1, 0, 1),
 }
 
 
