@@ -428,9 +428,13 @@ int num_cus() {
 // 16-byte slot sl of row r holds pixel quad sl ^ ((r >> 2) & 3).  MIXED: some tap shifts the
 // columns by a non-multiple of 4 (dilation 1, 2), so quads straddle the row ends: x is then
 // copied pixel by pixel (dword copies, 4 rows per instruction); padding = out-of-range offsets.
-template <int TAPS, bool MIXED>
+// WIDE (round 2, pruned widths): the four waves sit side by side along the B rows (64 each) and every wave holds
+// all 8 row blocks of dy, 8 x 2 MFMA tiles; row blocks at or past M = Cout are dead for the whole tile and their
+// MFMAs are skipped - the cost follows ceil(Cout / 32) instead of ceil(Cout / 256) * 8 (or a register-staged
+// 128- / 64-row tile).  Same staging, same K order per output element as the 2 x 2 layout.
+template <int TAPS, bool MIXED, bool WIDE = false>
 __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
-    constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
+    constexpr int TM = WIDE ? 8 : 4, TN = WIDE ? 2 : 4, WN = WIDE ? 4 : 2, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][BK]
     float* Bs = smem + 2 * BM * BK;     // [2][BN][BK]
@@ -574,6 +578,8 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int nb = (p.M - m0 + 31) >> 5;             // WIDE: live dy row blocks of this tile (block-uniform)
+    nb = nb > TM ? TM : nb;
 
     if (nk > 0) issue(0);
     retire();
@@ -602,10 +608,12 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
             constexpr int kq = s / 4, e = s % 4;
             static_for<0, TM>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
-                static_for<0, TN>([&](auto j_) {
-                    constexpr int j = decltype(j_)::value;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][i][e], bf[kq][j][e], acc[i][j], 0, 0, 0);
-                });
+                if (!WIDE || i < nb) {
+                    static_for<0, TN>([&](auto j_) {
+                        constexpr int j = decltype(j_)::value;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][i][e], bf[kq][j][e], acc[i][j], 0, 0, 0);
+                    });
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -632,9 +640,18 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
 }
 
 struct Plan {
-    int bm, bn, cfg;  // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave)
+    int bm, bn, cfg;  // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave), 3 = 256x128, 4 = 256x64
     int tiles_m, tiles_n, splits, kchunk;
+    bool wide;        // 256 x 256 tile on wgrad_dma_kernel<.., WIDE>: dead dy row blocks skipped (ragged / small Cout)
 };
+
+static bool math_bf16x3();
+
+// shapes the LDS-DMA kernels take apart from the tile choice: stride 1, output = input size, rows multiple of 16 px
+bool dma_geometry(const DcfpConvDesc* d) {
+    static const bool on = [] { const char* e = getenv("DCFP_WGRAD_DMA"); return !e || atoi(e) != 0; }();   // =0: off
+    return on && d->stride == 1 && d->Hout == d->H && d->Wout == d->W && d->W % 16 == 0;
+}
 
 Plan make_plan(const DcfpConvDesc* d) {
     Plan pl;
@@ -650,6 +667,21 @@ Plan make_plan(const DcfpConvDesc* d) {
     else if (lopsided && M > 128 && Nn > 64) { pl.cfg = 3; pl.bm = 256; pl.bn = 128; }
     else if (lopsided && M > 128 && Nn > 32) { pl.cfg = 4; pl.bm = 256; pl.bn = 64; }
     else { pl.cfg = 2; pl.bm = 64; pl.bn = 64; }
+    // WIDE: 32-row granularity in Cout on the LDS-DMA pipeline.  DCFP_WGRAD_WIDE: 0 off, 2 wherever eligible (A/B).
+    pl.wide = false;
+    {
+        static const int mode = [] { const char* e = getenv("DCFP_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
+        const bool mixed = d->KH == 3 && ((d->pad | d->dil) & 3) != 0;
+        const bool x_pitched = d->x_pitch && d->x_pitch != d->W;
+        const bool eligible = mode != 0 && !math_bf16x3() && dma_geometry(d) && Nn > 128 && (!mixed || x_pitched) &&
+                              !(d->KH == 3 && d->pad != d->dil);
+        if (eligible) {
+            const long long old_rows = (long long)((M + pl.bm - 1) / pl.bm) * pl.bm, new_rows = (long long)((M + 31) / 32) * 32;
+            if (mode == 2 || pl.cfg != 0 || (M % pl.bm != 0 && 10 * new_rows <= 9 * old_rows)) {
+                pl.wide = true; pl.cfg = 0; pl.bm = 256; pl.bn = 256;
+            }
+        }
+    }
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (Nn + pl.bn - 1) / pl.bn;
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
@@ -742,10 +774,10 @@ static bool wgrad_dma_ok(const DcfpConvDesc* d, int cfg) {
 }
 static bool wgrad_dma_mixed(const DcfpConvDesc* d) { return d->KH == 3 && ((d->pad | d->dil) & 3) != 0; }
 
-template <int TAPS, bool MIXED>
+template <int TAPS, bool MIXED, bool WIDE = false>
 int launch_dma(const WgradParams& p, long long blocks, hipStream_t stream) {
     const size_t lds = (size_t)2 * 512 * BK * sizeof(float);
-    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED, WIDE>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DCFP_OK : (int)e;
 }
@@ -769,7 +801,7 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 bool dcfp_wgrad_pitch_ok(const DcfpConvDesc* d) {
     if (check_desc(d) != DCFP_OK) return false;
     const Plan pl = make_plan(d);
-    if (wgrad3_ok(d, pl.cfg) || !wgrad_dma_ok(d, pl.cfg)) return false;
+    if (wgrad3_ok(d, pl.cfg) || !(pl.wide || wgrad_dma_ok(d, pl.cfg))) return false;
     const int xp = d->x_pitch ? d->x_pitch : d->W;
     if (xp != d->W && (d->KH != 3 || d->pad != d->dil || xp < d->W + d->pad)) return false;
     // 31-bit byte offsets relative to the first image of a split: checked in the launcher with the pitched strides
@@ -781,6 +813,7 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
                        pl.cfg == 4 ? "4,1,2,2" : "2,2,1,1";
     if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
+    if (pl.wide) return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,false,true>", d->KH * d->KW);
     if (wgrad_dma_ok(d, pl.cfg))
         return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,%s>", d->KH * d->KW,
                         (wgrad_dma_mixed(d) && !(d->x_pitch && d->x_pitch != d->W)) ? "true" : "false");
@@ -834,7 +867,11 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         rc = dcfp_wgrad3_launch(dy, p.dy_nstride, x, p.x_nstride, p.out, d->N, d->Cout, d->Cin, T, d->H, d->W,
                                 d->Hout, d->Wout, d->pad, d->dil, p.Kpix, pl.kchunk, pl.splits, pl.tiles_m,
                                 pl.tiles_n, dcfp_s(stream));
-    else if (wgrad_dma_ok(d, pl.cfg)) {
+    else if (pl.wide) {
+        const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
+        if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+        rc = T == 1 ? launch_dma<1, false, true>(p, blocks, dcfp_s(stream)) : launch_dma<9, false, true>(p, blocks, dcfp_s(stream));
+    } else if (wgrad_dma_ok(d, pl.cfg)) {
         const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
         if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
         // (pitched x: every shifted quad reads data or the rows' zero tails - the un-mixed kernel does it all)

@@ -169,7 +169,7 @@ def test_row_pitched_operands_bit_identical(cuda, shape):
     names = [ops.conv_kernel_name(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)]
     # un-mixed LDS-DMA kernels (the ragged-M one where the channel count is off the 256 grid); same K order everywhere
     assert all(n in ("igemm2_dma_kernel<9,false>", "igemm2_dma8_kernel<9>") for n in names[:2]), names
-    assert names[2] == "wgrad_dma_kernel<9,false>", names
+    assert names[2] in ("wgrad_dma_kernel<9,false>", "wgrad_dma_kernel<9,false,true>"), names
     xp = ops.pitched_buffer(tuple(x.shape), pitch, "test_x", cuda); xp.copy_(x)
     dyp = ops.pitched_buffer(tuple(dy.shape), pitch, "test_dy", cuda); dyp.copy_(dy)
     assert ops._pitch_of(xp) == pitch and float(xp.as_strided((N, Cin, H, pitch - W), xp.stride(), xp.storage_offset() + W).abs().sum()) == 0.0
@@ -259,6 +259,14 @@ def test_ragged_m_kernel(cuda, case, kernels):
     assert rel(y[:, :8], y64b) < tol
     assert rel(dx[:, ci], x64.grad) < max(tol, 1e-5), rel(dx[:, ci], x64.grad)
     assert rel(dxa[:, ci], x64.grad + seed[:, ci].double()) < max(tol, 1e-5)
+    # weight gradient: ragged Cout goes to the WIDE layout of the LDS-DMA wgrad kernel (dead dy row blocks skipped)
+    if Cout % 256 and Cin * k * k > 128 and W % 16 == 0:
+        assert ops.conv_kernel_name(desc, _lib.CONV_WGRAD) == f"wgrad_dma_kernel<{k * k},false,true>", \
+            ops.conv_kernel_name(desc, _lib.CONV_WGRAD)
+    dw = ops.conv2d_wgrad(dyin, xin, tuple(w.shape), 1, p, d)[0]
+    w64 = w[:, ci].double().requires_grad_(True)
+    F.conv2d(x[:, ci].double(), w64, None, 1, p, d).backward(dy.double())
+    assert rel(dw[:, ci], w64.grad) < 2e-5, rel(dw[:, ci], w64.grad)
 
 
 def test_bottleneck_pitched_path_equals_dense(cuda):
