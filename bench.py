@@ -137,12 +137,15 @@ def roofline_from_profile(recs, images_per_step, step_s):
     w, ms, cnt = convs[dom]
     # HBM-side bytes per launch from the committed PMC profile (cannot be collected inside this
     # process): corrected FETCH_SIZE + WRITE_SIZE of the same kernel instance on its dominant shape
-    traffic = None
+    traffic = traffic_note = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_conv_traffic.json")) as f:
             tk = json.load(f)["kernels"].get(dom)
         if tk:
             traffic = tk["fetch_bytes_corrected"] + tk["write_bytes"]
+            traffic_note = ("bytes/launch beyond L2 (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, "
+                            "profiles/r02_conv_traffic_pmc.txt): " + tk["note"] +
+                            f"; algorithmic bytes of that launch {tk['algorithmic_bytes'] / 1e6:.0f} MB")
     except Exception:
         pass
     # the split kernels issue 6 bf16 MFMA products per fp32 product: their ceiling is the dense
@@ -151,8 +154,7 @@ def roofline_from_profile(recs, images_per_step, step_s):
     peak = PEAK_BF16_MFMA / 6.0 if split else PEAK_F32_MFMA
     roof = {"bound": "mfma", "kernel": dom, "achieved": w / (ms * 1e-3) / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / peak, "traffic": traffic,
-            "traffic_note": "bytes/launch beyond L2 (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, "
-                            "profiles/r01_conv_traffic_pmc.txt; layer3 conv2 shape)" if traffic else None,
+            "traffic_note": traffic_note,
             "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "flop_per_launch": w / cnt,
             "dtype": "f32 as 3 bf16 planes (6 x v_mfma_f32_32x32x16_bf16 per product)" if split
                      else "f32 (v_mfma_f32_32x32x2_f32)"}
@@ -379,6 +381,7 @@ def main():
                                       "EIC step, SGD m0.9 wd5e-4",
                           "global_batch": global_batch, "parallelism": f"dp{world}"},
                "final_loss": last, "peak_mem_GiB": peak_mem,
+               "grad_allreduce_launches_per_step": getattr(getattr(model, "reducer", None), "launched", None) if ddp else None,
                "sgd_table_rebuilds": sgd_rebuilds,
                "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone, args.channel_cfg) == (1024, 2048, "resnet101", None) else None,
                "roofline": roof, "cpu_baseline": cpu, "alt_math": alt, "detail": extra}
