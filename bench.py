@@ -261,6 +261,11 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} contradicts WORLD_SIZE={world} set by the launcher")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON record: keep the real stdout aside and point fd 1 at stderr, so that
+    # library chatter (RCCL prints its version banner to stdout when the communicator is created) cannot get in
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path: no GPU visible")
     from dcfp_amd import _lib
@@ -385,7 +390,8 @@ def main():
                "sgd_table_rebuilds": sgd_rebuilds,
                "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone, args.channel_cfg) == (1024, 2048, "resnet101", None) else None,
                "roofline": roof, "cpu_baseline": cpu, "alt_math": alt, "detail": extra}
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 
