@@ -125,16 +125,17 @@ def roofline_from_profile(recs, images_per_step, step_s):
     for kind, key, work, ms in recs:
         if kind in which:
             name = ops.conv_kernel_name(key, which[kind])
-            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
             a[0] += work; a[1] += ms; a[2] += 1
+            a[3] += work * ops.conv_executed_fraction(key, which[kind])     # MFMA work really issued
             conv_flops += work; conv_ms += ms
         else:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += work; a[1] += ms; a[2] += 1
             bn_bytes += work; bn_ms += ms
     convs = {k: v for k, v in agg.items() if "kernel" in k}
     dom = max(convs, key=lambda k: convs[k][1])
-    w, ms, cnt = convs[dom]
+    w, ms, cnt, w_exec = convs[dom]
     # HBM-side bytes per launch from the committed PMC profile (cannot be collected inside this
     # process): corrected FETCH_SIZE + WRITE_SIZE of the same kernel instance on its dominant shape
     traffic = traffic_note = None
@@ -153,12 +154,17 @@ def roofline_from_profile(recs, images_per_step, step_s):
     split = dom.startswith(("igemm3_kernel", "wgrad3_kernel"))
     peak = PEAK_BF16_MFMA / 6.0 if split else PEAK_F32_MFMA
     roof = {"bound": "mfma", "kernel": dom, "achieved": w / (ms * 1e-3) / 1e12, "peak": peak / 1e12,
-            "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / peak, "traffic": traffic,
+            "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / peak,
+            # `achieved` counts the nominal multiply-adds of the convolutions (padded taps included - SURVEY 8d);
+            # executed_frac counts only the MFMAs issued (K-steps of kernel rows lying wholly in the padding are
+            # skipped for the ASPP / layer4 dilations): that is the matrix cores' real utilisation
+            "executed_frac": w_exec / (ms * 1e-3) / peak, "traffic": traffic,
             "traffic_note": traffic_note,
             "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "flop_per_launch": w / cnt,
             "dtype": "f32 as 3 bf16 planes (6 x v_mfma_f32_32x32x16_bf16 per product)" if split
                      else "f32 (v_mfma_f32_32x32x2_f32)"}
-    others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1], "launches": v[2]}
+    others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "executed_TFLOP/s": v[3] / (v[1] * 1e-3) / 1e12,
+                  "ms_per_step": v[1], "launches": v[2]}
               for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])}
     hbm = {k: {"GB/s": v[0] / (v[1] * 1e-3) / 1e9, "ms_per_step": v[1], "launches": v[2]}
            for k, v in agg.items() if "kernel" not in k}

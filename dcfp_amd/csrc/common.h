@@ -18,6 +18,17 @@ static inline hipStream_t dcfp_s(dcfp_stream_t s) { return reinterpret_cast<hipS
 
 static inline bool dcfp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// compute units of the current device (256 on MI355X; also the answer when no device is present)
+static inline int dcfp_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess &&
+             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -44,6 +44,9 @@ extern "C" int dcfp_abi_version(void) { return 2; }
 
 // implemented in conv_wgrad.hip / conv_igemm2.hip
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len);
+double dcfp_wgrad_exec_fraction(const DcfpConvDesc* d);
+double dcfp_igemm2_exec_fraction(int T, int M, int Ck, int N, int Hi, int Wi, int Ho, int Wo, int sn, int sd,
+                                 int off0, int offstep, bool pitched);
 size_t dcfp_igemm2_workspace_bytes(int T, int M, int Ck, long long px, int sd);
 const char* dcfp_igemm2_cfg_args(int M, long long px, int sd);
 int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
@@ -127,6 +130,21 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
                         (d->KH == 3 && ((d->pad | d->dil) & 3) != 0 && !pitched) ? "true" : "false");   // <TAPS, MIXED>
     }
     return snprintf(buf, buf_len, "igemm2_kernel<%d,%s>", d->KH * d->KW, dcfp_igemm2_cfg_args(M, px, sd));
+}
+
+extern "C" double dcfp_conv2d_executed_fraction(const DcfpConvDesc* d, int pass) {
+    if (check_desc(d) != DCFP_OK) return 1.0;
+    if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_exec_fraction(d);
+    const bool fwd = pass == DCFP_CONV_FWD;
+    const int M = fwd ? d->Cout : d->Cin;
+    const long long px = fwd ? (long long)d->N * d->Hout * d->Wout : (long long)d->N * d->H * d->W;
+    if (igemm3_ok(M, px, fwd ? d->stride : 1, fwd ? 1 : d->stride)) return 1.0;
+    const int sp = fwd ? d->x_pitch : d->dy_pitch;
+    const bool pitched = sp && sp != (fwd ? d->W : d->Wout);
+    return fwd ? dcfp_igemm2_exec_fraction(d->KH * d->KW, d->Cout, d->Cin, d->N, d->H, d->W, d->Hout, d->Wout, d->stride, 1,
+                                           -d->pad, d->dil, pitched)
+               : dcfp_igemm2_exec_fraction(d->KH * d->KW, d->Cin, d->Cout, d->N, d->Hout, d->Wout, d->H, d->W, 1, d->stride,
+                                           d->pad, -d->dil, pitched);
 }
 
 extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,

@@ -13,6 +13,8 @@
 //    issued before the 16 MFMAs of step kk), and the next tile's global loads / LDS stores are
 //    spread over the eight 16-MFMA slots of a K-step instead of forming one serial block.
 #include "igemm2_common.h"
+#include <queue>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -596,11 +598,19 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
     float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
     const int group = 8 * p.tiles_m;
     const int g = blockIdx.x / group, local = blockIdx.x - g * group;
-    const int nt = g * 8 + (local & 7);
+    int nt = g * 8 + (local & 7);
     const int mt = local >> 3;
     if (nt >= p.tiles_n_total) return;
-    const int img = nt / p.tiles_per_img;
-    const int ti = nt - img * p.tiles_per_img;
+    int img = nt / p.tiles_per_img;
+    int ti = nt - img * p.tiles_per_img;
+    if (TAPS == 9 && p.tapskip == 2) {
+        // centre-out order over all images: the tiles that keep all three kernel rows are dispatched first, the
+        // cheaper edge tiles fill the tail of the launch (longest-first scheduling; `nt` stays the tile's identity)
+        const int k = nt / p.N, c = p.tiles_per_img >> 1;
+        img = nt - k * p.N;
+        ti = (k & 1) ? c - 1 - (k >> 1) : c + (k >> 1);
+        nt = img * p.tiles_per_img + ti;
+    }
     // Pixel tile: 256 consecutive pixels, or (tile2d, shifted taps only) 8 rows x 32 columns, so that only the
     // tiles on the image's left / right edge see quads that straddle the border and all others can copy 16
     // bytes per lane from the shifted source.  loc -> offset of tile pixel `loc` from the tile's first pixel.
@@ -646,10 +656,27 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         }
     }
     const int kpt = p.CkP / BK;
-    const int nk = TAPS * kpt;
+    // Dead tap rows (round 2): with a dilation comparable to the image height (ASPP: 12 / 24 / 36 on 128 rows)
+    // every source row of kernel row kh lies in the padding for the tiles near the top / bottom edge - all its
+    // K-steps would copy zeros and multiply them.  Those K-steps are skipped (6 / 12 / 19 % of the layer's
+    // MFMAs); the remaining ones keep their order, so the sums are the same bits (x + 0 * w == x for finite w).
+    int t_beg = 0, t_end = TAPS;
+    if (TAPS == 9 && p.tapskip) {
+        const int rows = t2d ? (BN >> tsh) : 0;
+        const int oh_lo = t2d ? (ti / (p.Wi >> tsh)) * rows : p0 / p.Wo;
+        int oh_hi = t2d ? oh_lo + rows - 1 : (p0 + BN - 1 < p.P ? p0 + BN - 1 : p.P - 1) / p.Wo;
+        oh_hi = oh_hi < p.Ho ? oh_hi : p.Ho - 1;
+        // (the row offsets run upwards for the forward pass and downwards for dgrad: the live rows are contiguous)
+        auto live = [&](int kh) { const int o = p.off0 + kh * p.offstep; return oh_hi + o >= 0 && oh_lo + o < p.Hi; };
+        int kh_lo = 0, kh_hi = 2;
+        while (kh_lo < 2 && !live(kh_lo)) ++kh_lo;
+        while (kh_hi > kh_lo && !live(kh_hi)) --kh_hi;
+        t_beg = 3 * kh_lo; t_end = 3 * kh_hi + 3;
+    }
+    const int nk = (t_end - t_beg) * kpt;
     unsigned boff4 = 0, boff1[4] = {0, 0, 0, 0};
     bool tap_quads = true;            // block-uniform: this tap's column shift keeps quads aligned
-    int ld_t = 0, ld_cb = 0;          // (tap, channel block) of the tile the loader copies next
+    int ld_t = t_beg, ld_cb = 0;      // (tap, channel block) of the tile the loader copies next
     auto set_tap = [&](int t) {
         const int kh = (TAPS == 9) ? t / 3 : 0;
         const int kw = (TAPS == 9) ? t - kh * 3 : 0;
@@ -718,7 +745,7 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         });
         if (++ld_cb == kpt) {
             ld_cb = 0;
-            if (++ld_t < TAPS) set_tap(ld_t);
+            if (++ld_t < t_end) set_tap(ld_t);
         }
     };
     auto retire = [&]() {   // every copy landed and every fragment read done, then the barrier
@@ -732,7 +759,7 @@ __global__ void __launch_bounds__(256) igemm2_dma_kernel(const Igemm2Params p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    set_tap(0);
+    set_tap(t_beg);
     issue(0);
     retire();
     const int a_off = wm * (TM * 32) + TM * l31;
@@ -982,6 +1009,116 @@ bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int
     return 10 * new_rows <= 9 * old_rows;
 }
 
+// Dead kernel rows (9-tap LDS-DMA kernels): 0 = no skipping, 1 = skip in tile order, 2 = skip with the tiles dispatched
+// centre-out (full tiles first).  Skipping shortens SOME tiles; whether that shortens the launch depends on how the
+// tiles pack onto the CUs: ASPP forward has 512 tiles = exactly two per CU, and with 320 of them still full
+// (dilation 24) every order ends in two full rounds - skipping then only takes the workgroups out of lockstep
+// (they share the weight slices through L2) and costs 1..5 %.  The three options are therefore list-scheduled on
+// the host (workgroups go to the first free CU in blockIdx order, one per CU) and skipping is used where it
+// predicts >= 3 % (measured: dilation 36 forward -17 %, layer4 dilation 16 -8 %, ASPP dgrad -4 / -10 / -17 %).
+// DCFP_IGEMM_TAPSKIP = 0 / 1 / 2 forces a mode (A/B).
+bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
+
+// kernel rows (of 3) that tile `ti` of an image executes - the same arithmetic as the kernels' t_beg / t_end
+static int tile_live_rows(const Igemm2Params& p, int ti) {
+    int oh_lo, oh_hi;
+    if (p.tile2d) {
+        const int rows = 256 >> p.tile2d;
+        oh_lo = (ti / (p.Wi >> p.tile2d)) * rows;
+        oh_hi = oh_lo + rows - 1;
+    } else {
+        const int p0 = ti * 256;
+        oh_lo = p0 / p.Wo;
+        oh_hi = (p0 + 255 < p.P ? p0 + 255 : p.P - 1) / p.Wo;
+    }
+    oh_hi = oh_hi < p.Ho ? oh_hi : p.Ho - 1;
+    int lo = 0, hi = 2;
+    auto live = [&](int kh) { const int o = p.off0 + kh * p.offstep; return oh_hi + o >= 0 && oh_lo + o < p.Hi; };
+    while (lo < 2 && !live(lo)) ++lo;
+    while (hi > lo && !live(hi)) --hi;
+    return hi - lo + 1;
+}
+
+static int pick_tapskip(const Igemm2Params& p, int bn) {
+    static const int forced = [] { const char* e = getenv("DCFP_IGEMM_TAPSKIP"); return e ? atoi(e) : -1; }();
+    if (bn != 256) return 0;                      // only the 256-pixel-tile LDS-DMA kernels skip
+    const bool t2d = p.tile2d != 0;
+    if (forced >= 0) return (forced == 2 && t2d) ? 1 : forced;
+    if (t2d) return 1;                            // (8-row tiles of the dilation 1 / 2 convs: nothing to order)
+    struct Key { int Ho, Wo, Hi, N, tm, off0, offstep, mode; };
+    thread_local Key cache[16];
+    thread_local int used = 0;
+    for (int i = 0; i < used; ++i) {
+        const Key& k = cache[i];
+        if (k.Ho == p.Ho && k.Wo == p.Wo && k.Hi == p.Hi && k.N == p.N && k.tm == p.tiles_m && k.off0 == p.off0 &&
+            k.offstep == p.offstep)
+            return k.mode;
+    }
+    const int T = p.tiles_per_img, cus = dcfp_num_cus();
+    std::vector<float> work((size_t)T);
+    bool any = false;
+    for (int ti = 0; ti < T; ++ti) {
+        const int live = tile_live_rows(p, ti);
+        any |= live < 3;
+        work[ti] = (float)live + 0.1f;            // + prologue / epilogue
+    }
+    int mode = 0;
+    if (any) {
+        auto makespan = [&](int m) {
+            std::priority_queue<float, std::vector<float>, std::greater<float>> free_at;
+            for (int i = 0; i < cus; ++i) free_at.push(0.f);
+            float end = 0.f;
+            const long long groups = ((long long)p.tiles_n_total + 7) / 8;
+            for (long long g = 0; g < groups; ++g)
+                for (int mt = 0; mt < p.tiles_m; ++mt)
+                    for (int l = 0; l < 8; ++l) {
+                        const long long nt = g * 8 + l;
+                        if (nt >= p.tiles_n_total) continue;
+                        int ti = (int)(nt % T);
+                        if (m == 2) {
+                            const int k = (int)(nt / p.N), c = T >> 1;
+                            ti = (k & 1) ? c - 1 - (k >> 1) : c + (k >> 1);
+                        }
+                        const float t0 = free_at.top();
+                        free_at.pop();
+                        const float t1 = t0 + (m == 0 ? 3.1f : work[ti]);
+                        free_at.push(t1);
+                        end = t1 > end ? t1 : end;
+                    }
+            return end;
+        };
+        const float m0 = makespan(0), m1 = makespan(1), m2 = makespan(2);
+        const float best = m2 <= m1 ? m2 : m1;
+        if (best <= 0.97f * m0) mode = m2 <= m1 ? 2 : 1;
+    }
+    if (used < 16) {
+        cache[used++] = Key{p.Ho, p.Wo, p.Hi, p.N, p.tiles_m, p.off0, p.offstep, mode};
+    }
+    return mode;
+}
+
+// Fraction of the nominal K-steps (9 taps x channels, padded taps included - the usual FLOP convention) that the
+// kernel chosen for this problem executes: < 1 where dead kernel rows are skipped.  For honest accounting only.
+double dcfp_igemm2_exec_fraction(int T, int M, int Ck, int N, int Hi, int Wi, int Ho, int Wo, int sn, int sd,
+                                 int off0, int offstep, bool pitched) {
+    if (T != 9 || sn != 1 || sd != 1) return 1.0;
+    const long long px = (long long)N * Ho * Wo;
+    const bool d8 = dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo, pitched);
+    if (!d8 && !dcfp_igemm2_dma_shape(T, M, Ck, Ho * Wo, px, sn, sd, off0, Hi * Wi, Wo)) return 1.0;
+    Igemm2Params p = {};
+    p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo; p.off0 = off0; p.offstep = offstep;
+    p.tiles_per_img = (p.P + 255) / 256; p.tiles_n_total = p.tiles_per_img * N; p.tiles_m = (M + 255) / 256;
+    {
+        static const int t2d = [] { const char* e = getenv("DCFP_IGEMM_2D"); return e ? atoi(e) : 5; }();
+        const bool fits = (t2d == 4 || t2d == 5) && Hi % (256 >> t2d) == 0 && Wi % (1 << t2d) == 0;
+        p.tile2d = (!d8 && fits && !pitched && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
+    }
+    if (pick_tapskip(p, 256) == 0) return 1.0;
+    long long live = 0;
+    for (int ti = 0; ti < p.tiles_per_img; ++ti) live += tile_live_rows(p, ti);
+    return (double)live / (3.0 * p.tiles_per_img);
+}
+
 // Layout of the Wp copy dcfp_igemm2_run would build for this problem (everything but the pointers)
 void dcfp_igemm2_wp_layout(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
                            int Wo, bool pitched, int sAm, int sAc, DcfpWpEntry* e) {
@@ -1045,6 +1182,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         const bool fits = (t2d == 4 || t2d == 5) && Hi % (256 >> t2d) == 0 && Wi % (1 << t2d) == 0;
         p.tile2d = (fits && !pitched && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
     }
+    p.tapskip = 0;      // decided below, once the tiling is known
     p.tiles_per_img = (p.P + (d8 ? 256 : c.bn) - 1) / (d8 ? 256 : c.bn);
     p.Hc = p.Wc = p.tiles_per_phase = p.zfold = 0;
     if (sd > 1) {     // strided dgrad: sd*sd phases, each tiled over its own coarse grid
@@ -1062,6 +1200,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     p.sn = sn; p.sd = sd; p.off0 = off0; p.offstep = offstep;
     p.accumulate = accumulate;
     p.vec_store = (p.P % 4 == 0) && (out_nstride % 4 == 0) && dcfp_aligned16(out);
+    if (T == 9 && sd == 1 && sn == 1) p.tapskip = pick_tapskip(p, d8 ? 256 : c.bn);
     const size_t need = (size_t)T * p.CkP * p.Mpad * sizeof(float);
     if (!workspace || workspace_bytes < need || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
     float* wp = static_cast<float*>(workspace);

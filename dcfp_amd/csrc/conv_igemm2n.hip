@@ -44,11 +44,18 @@ __global__ void __launch_bounds__(256) igemm2_dma8_kernel(const Igemm2Params p) 
     float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
     const int group = 8 * p.tiles_m;
     const int g = blockIdx.x / group, local = blockIdx.x - g * group;
-    const int nt = g * 8 + (local & 7);
+    int nt = g * 8 + (local & 7);
     const int mt = local >> 3;
     if (nt >= p.tiles_n_total) return;
-    const int img = nt / p.tiles_per_img;
-    const int p0 = (nt - img * p.tiles_per_img) * BN;
+    int img = nt / p.tiles_per_img;
+    int ti = nt - img * p.tiles_per_img;
+    if (TAPS == 9 && p.tapskip == 2) {     // centre-out dispatch order (see igemm2_dma_kernel)
+        const int k = nt / p.N, c = p.tiles_per_img >> 1;
+        img = nt - k * p.N;
+        ti = (k & 1) ? c - 1 - (k >> 1) : c + (k >> 1);
+        nt = img * p.tiles_per_img + ti;
+    }
+    const int p0 = ti * BN;
     const int m0 = mt * BM;
     int nb = (p.M - m0 + 31) >> 5;                 // live row blocks of this tile (block-uniform)
     nb = nb > NRB ? NRB : nb;
@@ -73,9 +80,22 @@ __global__ void __launch_bounds__(256) igemm2_dma8_kernel(const Igemm2Params p) 
         q_oh = pp / p.Wo; q_ow = pp - q_oh * p.Wo;
     }
     const int kpt = p.CkP / BK;
-    const int nk = TAPS * kpt;
+    // kernel rows that lie wholly in the padding for this tile are skipped (see igemm2_dma_kernel)
+    int t_beg = 0, t_end = TAPS;
+    if (TAPS == 9 && p.tapskip) {
+        const int oh_lo = p0 / p.Wo;
+        int oh_hi = (p0 + BN - 1 < p.P ? p0 + BN - 1 : p.P - 1) / p.Wo;
+        oh_hi = oh_hi < p.Ho ? oh_hi : p.Ho - 1;
+        // (the row offsets run upwards for the forward pass and downwards for dgrad: the live rows are contiguous)
+        auto live = [&](int kh) { const int o = p.off0 + kh * p.offstep; return oh_hi + o >= 0 && oh_lo + o < p.Hi; };
+        int kh_lo = 0, kh_hi = 2;
+        while (kh_lo < 2 && !live(kh_lo)) ++kh_lo;
+        while (kh_hi > kh_lo && !live(kh_hi)) --kh_hi;
+        t_beg = 3 * kh_lo; t_end = 3 * kh_hi + 3;
+    }
+    const int nk = (t_end - t_beg) * kpt;
     unsigned boff4 = 0;
-    int ld_t = 0, ld_cb = 0;          // (tap, channel block) of the K-step the loader copies next
+    int ld_t = t_beg, ld_cb = 0;      // (tap, channel block) of the K-step the loader copies next
     auto set_tap = [&](int t) {
         const int kh = (TAPS == 9) ? t / 3 : 0;
         const int kw = (TAPS == 9) ? t - kh * 3 : 0;
@@ -105,7 +125,7 @@ __global__ void __launch_bounds__(256) igemm2_dma8_kernel(const Igemm2Params p) 
         });
         if (++ld_cb == kpt) {
             ld_cb = 0;
-            if (++ld_t < TAPS) set_tap(ld_t);
+            if (++ld_t < t_end) set_tap(ld_t);
         }
     };
     auto retire = [&]() {
@@ -119,7 +139,7 @@ __global__ void __launch_bounds__(256) igemm2_dma8_kernel(const Igemm2Params p) 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    set_tap(0);
+    set_tap(t_beg);
     issue(0);
     retire();
     const int a_off = 8 * l31;                  // the lane's 8 A values: channels 32 i + l31, i = 0..7

@@ -820,6 +820,9 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     return snprintf(buf, buf_len, "wgrad2_kernel<%d,%s>", d->KH * d->KW, args);
 }
 
+// (the weight-gradient kernels execute every K-step: a tile of dW mixes all nine taps)
+double dcfp_wgrad_exec_fraction(const DcfpConvDesc*) { return 1.0; }
+
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
 
 extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {

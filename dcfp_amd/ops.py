@@ -55,6 +55,11 @@ def conv_kernel_name(d, which):
     return buf.value.decode() if n > 0 else "?"
 
 
+def conv_executed_fraction(d, which):
+    """Share of the nominal multiply-adds the dispatched kernel issues (< 1 where dead kernel rows are skipped)."""
+    return float(_lib.lib().dcfp_conv2d_executed_fraction(C.byref(d), which))
+
+
 def _conv_flops(d):
     return 2.0 * d.N * d.Cout * d.Hout * d.Wout * d.Cin * d.KH * d.KW
 
@@ -187,6 +192,8 @@ FUSE_BN_STATS = os.environ.get("DCFP_FUSED_BN_STATS", "1") not in ("0",)
 # The residual BatchNorm of a Bottleneck keeps its ReLU mask as one bit per element for the backward
 # (instead of two re-reads of the 4-byte block output); DCFP_BN_RELU_BITMASK=0 switches it off.
 BN_RELU_BITMASK = os.environ.get("DCFP_BN_RELU_BITMASK", "1") not in ("0",)
+# =0: the SyncBN backward exchange of the two per-channel sums is waited for before anything else is enqueued (A/B)
+SYNCBN_ASYNC = os.environ.get("DCFP_SYNCBN_ASYNC", "1") not in ("0",)
 
 
 _WP_OWNERS = weakref.WeakSet()     # weight tensors that carry permuted copies (w._dcfp_wp)
@@ -679,7 +686,8 @@ def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None
     dbeta = arena.grad_commit(bp, tb, kb, add_into)
     work = None
     if training and group is not None:
-        s1, s2, work = sync_bn_bwd_sums(s1, s2, group, async_op=True)
+        s1, s2, work = sync_bn_bwd_sums(s1, s2, group, async_op=SYNCBN_ASYNC)[:3] if SYNCBN_ASYNC else \
+            sync_bn_bwd_sums(s1, s2, group) + (None,)
     elif not training:   # running statistics are constants: dx = g * gamma * istd
         s1 = torch.zeros_like(s1); s2 = torch.zeros_like(s2)
     return (s1, s2, work, relu, y, dgamma, dbeta)

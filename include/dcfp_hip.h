@@ -107,6 +107,14 @@ int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d);
  * Returns the length written (excluding NUL), or <0 on a bad descriptor. */
 int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* buf, int buf_len);
 
+/* Fraction (0 < f <= 1) of the pass's nominal multiply-adds - 2*N*Cout*Hout*Wout*Cin*KH*KW, padded taps included,
+ * the usual convention and the one bench.py's `roofline.achieved` uses - that the dispatched kernel really issues.
+ * < 1 for dilated 3x3 convs whose dilation is comparable to the image height (ASPP 12 / 24 / 36 on 128 rows,
+ * networks/tools/aspp.py:37-39): the 9-tap LDS-DMA kernels skip, per pixel tile, the kernel rows that lie
+ * wholly in the zero padding (x + 0*w == x: same bits for finite weights).  Accounting only (bench.py reports
+ * `executed_frac` beside `frac`); DCFP_IGEMM_TAPSKIP=0 disables the skipping. */
+double dcfp_conv2d_executed_fraction(const DcfpConvDesc* d, int pass);
+
 /* y = conv(x, w) (+ bias[co] when bias != NULL).  y_nstride: batch stride of y in
  * elements (0 => Cout*Hout*Wout), lets a branch write into a channel slice of a
  * wider tensor (ASPP concat, aspp.py:77). */

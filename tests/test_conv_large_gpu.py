@@ -302,7 +302,78 @@ def test_bottleneck_pitched_path_equals_dense(cuda):
         assert torch.equal(a, b)
 
 
+
+# (N, Cin, H, W, Cout, dilation): ASPP-like geometry - the dilation is comparable to the image height, so whole kernel
+# rows fall into the padding for the tiles near the top / bottom edge.  One-row tiles (W = 256), two-row tiles,
+# a ragged last tile (P % 256 != 0), shifted (dilation % 4 != 0) taps on linear and on 8 x 32 tiles, and a
+# dilation larger than the image (only the centre row is ever live).
+TAPSKIP_SHAPES = [(2, 48, 96, 256, 512, 24), (2, 48, 96, 256, 512, 36), (6, 40, 64, 128, 256, 12),
+                  (8, 32, 50, 64, 512, 16), (3, 32, 44, 256, 512, 6), (3, 32, 64, 64, 1024, 18),
+                  (3, 32, 32, 256, 512, 40), (2, 32, 96, 256, 300, 24)]
+
+
+def _tapskip_child():
+    """Dilated 3x3 convs through the 9-tap LDS-DMA kernels: digests of forward, forward + BatchNorm statistics,
+    dgrad, accumulate-dgrad and wgrad for the parent to compare between DCFP_IGEMM_TAPSKIP / DCFP_WGRAD_TAPSKIP = 0 / 1."""
+    import hashlib
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dcfp_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    out = {}
+    for (N, Cin, H, W, Cout, d) in TAPSKIP_SHAPES:
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev)
+        desc = ops._desc(x.shape, w.shape, 1, d, d)
+        name = ops.conv_kernel_name(desc, _lib.CONV_FWD)
+        assert name.startswith("igemm2_dma_kernel<9") or name.startswith("igemm2_dma8_kernel<9"), name
+        y = ops.conv2d_fwd(x, w, None, 1, d, d)
+        r = ops.conv2d_fwd(x, w, None, 1, d, d, want_stats=True)
+        y2, stats = r if isinstance(r, tuple) else (r, None)
+        dy = torch.randn(y.shape, generator=g).to(dev)
+        dx = ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, d, d)
+        seed = torch.randn(x.shape, generator=g).to(dev)
+        ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, d, d, out=seed, accumulate=True)
+        dw, _ = ops.conv2d_wgrad(dy, x, tuple(w.shape), 1, d, d)
+        torch.cuda.synchronize()
+        items = [y, y2, dx, seed] + ([stats[0], stats[1]] if stats is not None else [])
+        # reference: fp64 on the CPU (the skipped K-steps must not change the result at all, and the result is right)
+        ref = torch.nn.functional.conv2d(x.cpu().double(), w.cpu().double(), None, 1, d, d)
+        err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+        refw = torch.nn.grad.conv2d_weight(x.cpu().double(), w.shape, dy.cpu().double(), 1, d, d)
+        errw = float((dw.cpu().double() - refw).abs().max() / refw.abs().max())
+        out[f"{N}x{Cin}x{H}x{W}->{Cout} d{d}"] = {"hash": [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in items],
+                                                  "wgrad_hash": hashlib.sha256(dw.cpu().numpy().tobytes()).hexdigest(),
+                                                  "err": err, "errw": errw, "kernel": name,
+                                                  "wkernel": ops.conv_kernel_name(desc, _lib.CONV_WGRAD)}
+    print("TAPSKIP_RESULT " + json.dumps(out))
+
+
+def test_dead_tap_rows_skipped_without_changing_a_bit(cuda):
+    """igemm2_dma_kernel<9, ...> skips the K-steps of kernel rows that lie wholly in the padding for a tile
+    (ASPP dilations 12 / 24 / 36 on 128 rows: 6 / 12 / 19 % of the MFMAs).  The remaining K-steps keep their order,
+    so forward, fused statistics, dgrad and accumulate-dgrad must be the same bits as with DCFP_IGEMM_TAPSKIP=0;
+    the weight-gradient kernel trims each tap's pixel range instead (a different split of the same sum: compared
+    with the fp64 reference at the usual tolerance, and both settings against it)."""
+    res = []
+    for v in ("0", "1"):
+        env = dict(os.environ, DCFP_IGEMM_TAPSKIP=v, DCFP_WGRAD_TAPSKIP=v, DCFP_CONV_MATH="f32")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--tapskip-child"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("TAPSKIP_RESULT ")][-1]
+        res.append(json.loads(line[len("TAPSKIP_RESULT "):]))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == len(TAPSKIP_SHAPES)
+    for k in res[0]:
+        assert res[0][k]["hash"] == res[1][k]["hash"], (k, res[0][k]["kernel"])
+        assert res[1][k]["err"] < 2e-6 and res[1][k]["errw"] < 2e-5, (k, res[1][k])
+        assert res[0][k]["errw"] < 2e-5, (k, res[0][k])
+    assert any(len(v["hash"]) == 6 for v in res[0].values())        # the fused-statistics epilogue was exercised
+
 if __name__ == "__main__" and "--child" in sys.argv:
     _child()
 if __name__ == "__main__" and "--persist-child" in sys.argv:
     _persist_child()
+if __name__ == "__main__" and "--tapskip-child" in sys.argv:
+    _tapskip_child()

@@ -1,0 +1,181 @@
+"""Two data-parallel ranks on ONE MI355X (both processes on cuda:0, gloo carrying the device tensors): the only
+way to run the N > 1 model path - SyncBN exchange with two real contributions, gradient arena averaged over two
+ranks, broadcast of rank 0's weights - on hardware before the 8-GPU node does (engine.py:63-68, train.py:259-268).
+Rank r trains on images [2r, 2r+2) of a 4-image batch; a single process trains on all 4.  With no ignored
+pixels the two are the same mathematical step (pooled BN statistics = full-batch statistics, mean of the two
+rank losses = full-batch loss, averaged gradient = full-batch gradient).  Forward quantities (loss, running
+statistics) must agree to fp32 summation noise.  Gradients of this 50-layer net at 17 x 33 feature maps are
+ill-conditioned (near-dead channels: 1/sqrt(var + eps) amplifies rounding; the single-process fp32 step itself
+sits 1-3 % from the fp64 oracle, as torch's own fp32 CPU step does), so they are judged against the TRUTH: the
+data-parallel gradient must be as close to the fp64 CPU oracle as the single-process gradient is (noise-bounded,
+per tensor and globally).  The two ranks must agree with each other BIT FOR BIT after two optimizer steps
+(gradients, weights, running statistics, EIC) - the invariant data parallelism rests on.  RCCL refuses two ranks on one device, hence gloo;
+the collectives' call sites, buffers, ordering and stream hand-over are the ones RCCL runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PORT = "29547"
+
+
+def _child(rank, world, out_path):
+    sys.path.insert(0, ROOT)
+    import argparse
+    import torch
+    import torch.distributed as dist
+    from dcfp_amd import networks, pruners, optimizer as opt
+    from dcfp_amd.engine import Engine, DataParallel
+    from dcfp_amd.loss.criterion import build_criterions
+    from oracle import fill, model as omodel
+    from oracle.train_step import CpuTrainer
+
+    class DS:
+        ignore_label = 255; num_classes = 19; class_weights = None
+
+    class A:
+        no_decay = None; optim = "sgd"; momentum = 0.9; learning_rate = 1e-3; weight_decay = 5e-4
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    bb = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
+    # Seeded random weights and inputs (no ignored pixels: equal valid-pixel counts on both ranks).  The closed-form
+    # fill of the oracle tests is deliberately not used here: its many exactly-tied / near-zero pre-activations flip
+    # ReLU masks under 1e-7 perturbations, which turns summation-order noise into percent-level
+    # gradient differences and would hide what this test is after.
+    gen = torch.Generator().manual_seed(11)
+    X = torch.randn(4, 3, 129, 257, generator=gen).to(dev)
+    L = torch.randint(0, 19, (4, 129, 257), generator=gen).to(dev)
+    if os.environ.get("DCFP_DDP2_CLOSED_FORM"):
+        X = fill.closed_form_input(4, 129, 257).to(dev)
+        L = fill.closed_form_labels(4, 129, 257).to(dev)
+        L = torch.where(L == 255, torch.zeros_like(L), L)
+
+    def run(ddp):
+        torch.manual_seed(5)                       # default (kaiming) conv init, the same for every run and rank
+        m = networks.deeplabv3.Seg_Model(backbone="resnet50", backbone_para=dict(bb), num_classes=19, align_corner=True,
+                                         criterion=build_criterions("ce", DS(), {"ds_weight": 0.4}), deepsup=True)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        for k, v in sd.items():                    # non-trivial BN affine parameters and conv weights at init scale
+            if v.dtype.is_floating_point and v.dim() == 1 and k.endswith(".weight"):
+                v.uniform_(0.5, 1.5)
+            elif v.dtype.is_floating_point and v.dim() == 1 and k.endswith(".bias"):
+                v.normal_(0.0, 0.1)
+        if os.environ.get("DCFP_DDP2_CLOSED_FORM"):
+            sd = fill.closed_form_state(m.state_dict())
+        sd0 = {k: v.clone() for k, v in sd.items()}
+        if ddp and rank != 0:                      # rank 0's weights must arrive by the constructor's broadcast
+            sd = {k: (v * 0.5 if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        m.load_state_dict(sd)
+        m.conv_deepsup[3].p = 0.0
+        m = m.to(dev).train()
+        optimizer = opt.build_optimizer(A, m)
+        tp = pruners.dcfp_pruning(m, 0.999)
+        if ddp:
+            sys.argv = ["x"]
+            eng = Engine(custom_parser=argparse.ArgumentParser())
+            assert eng.distributed and eng.world_size == world
+            model = eng.data_parallel(m)
+            assert isinstance(model, DataParallel)
+            x, lab = X[2 * rank:2 * rank + 2].contiguous(), L[2 * rank:2 * rank + 2].contiguous()
+        else:
+            model, x, lab = m, X, L
+        losses = []
+        for it in range(2):
+            optimizer.zero_grad()
+            loss = model(x, lab, deepsup=True)["loss"]
+            red = eng.all_reduce_tensor(loss) if ddp else loss
+            losses.append(red.item())
+            loss.backward()
+            tp.step(m)
+            if it == 0:
+                grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+                run1 = {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k}
+            optimizer.step()
+        torch.cuda.synchronize()
+        eic = torch.cat([tp.get_eic()["eic"][n].reshape(-1) for n in tp._names]).clone()
+        state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        return losses, grads, eic, state, run1, sd0
+
+    full = run(False) if rank == 0 else None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=PORT, RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ddp = run(True)
+
+    # rank-to-rank bit identity: gather rank 1's flat state on rank 0
+    flat = torch.cat([v.reshape(-1).double() for v in ddp[3].values()] + [ddp[2].double()])
+    gflat = torch.cat([g.reshape(-1) for g in ddp[1].values()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    gboth = [torch.empty_like(gflat) for _ in range(world)]
+    dist.all_gather(gboth, gflat)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    # the truth: one fp64 CPU step of the oracle on the full batch
+    cfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
+    tr = CpuTrainer(full[5], cfg, lr=1e-3, dtype=torch.float64)
+    oloss, _, _ = tr.step(X.double().cpu(), L.cpu(), update=False)
+    og = {k: tr.sd[k].grad.to(dev) for k in full[1]}
+    cat = lambda d: torch.cat([d[k].reshape(-1).double() for k in full[1]])
+    e_full = {k: rel(full[1][k], og[k]) for k in og}
+    e_ddp = {k: rel(ddp[1][k], og[k]) for k in og}
+    ratio = {k: e_ddp[k] / (e_full[k] + 1e-4) for k in og}
+    worst = max(ratio, key=ratio.get)
+    r1 = {k: rel(ddp[4][k], full[4][k]) for k in full[4]}
+    r1w = max(r1, key=r1.get)
+    if os.environ.get("DCFP_DDP2_DIAG"):
+        with open(os.environ["DCFP_DDP2_DIAG"], "w") as f:
+            json.dump({"grad": [[k, e_full[k], e_ddp[k]] for k in og], "run1": r1}, f)
+    out = {"ranks_state_equal": bool(torch.equal(both[0], both[1])),
+           "ranks_grad_equal": bool(torch.equal(gboth[0], gboth[1])),
+           "loss_full": full[0], "loss_ddp": ddp[0], "loss_oracle": oloss,
+           "grad_err_global": [rel(cat(full[1]), cat(og)), rel(cat(ddp[1]), cat(og))],
+           "grad_ratio_worst": [worst, ratio[worst], e_full[worst], e_ddp[worst]],
+           "running_after_step1_worst": [r1w, r1[r1w]],
+           "nbt": [int(ddp[3]["backbone.bn1.num_batches_tracked"]), int(full[3]["backbone.bn1.num_batches_tracked"])],
+           "n_params": len(full[1])}
+    with open(out_path, "w") as f:
+        json.dump(out, f)
+
+
+def test_two_ranks_match_the_full_batch_and_each_other(cuda, tmp_path):
+    env = dict(os.environ)
+    env.pop("DCFP_FORCE_SYNCBN", None)
+    out = str(tmp_path / "ddp2.json")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "2", out], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=900)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, logs[r][-3000:])
+    rec = json.load(open(out))
+    print("DDP2", json.dumps(rec))
+    assert rec["ranks_state_equal"] and rec["ranks_grad_equal"]          # bit for bit, after 2 optimizer steps
+    assert abs(rec["loss_ddp"][0] - rec["loss_full"][0]) <= 2e-6 * abs(rec["loss_full"][0]), rec
+    assert abs(rec["loss_ddp"][0] - rec["loss_oracle"]) <= 5e-6 * abs(rec["loss_oracle"]), rec
+    assert abs(rec["loss_ddp"][1] - rec["loss_full"][1]) <= 2e-4 * abs(rec["loss_full"][1]), rec   # after one SGD step
+    assert rec["running_after_step1_worst"][1] < 2e-4, rec              # pooled statistics = full-batch statistics
+    e_full, e_ddp = rec["grad_err_global"]
+    assert e_ddp <= 1.5 * e_full + 1e-4, rec                            # as close to the fp64 truth as one process is
+    assert rec["grad_ratio_worst"][1] < 3.0, rec                        # ... for every single tensor
+    assert rec["nbt"] == [2, 2] and rec["n_params"] > 150
+
+
+if __name__ == "__main__" and "--child" in sys.argv:
+    i = sys.argv.index("--child")
+    _child(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3])

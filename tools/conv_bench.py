@@ -17,6 +17,9 @@ SHAPES = {
     "l3c3_1x1": (4, 256, 128, 256, 1024, 1, 1, 0, 1),
     "l3c1_1x1": (4, 1024, 128, 256, 256, 1, 1, 0, 1),
     "aspp_3x3d12": (4, 2048, 128, 256, 256, 3, 1, 12, 12),
+    "aspp_3x3d24": (4, 2048, 128, 256, 256, 3, 1, 24, 24),
+    "aspp_3x3d36": (4, 2048, 128, 256, 256, 3, 1, 36, 36),
+    "l4c2_3x3d16": (4, 512, 128, 256, 512, 3, 1, 16, 16),
     "ds_3x3": (4, 1024, 128, 256, 512, 3, 1, 1, 1),
     "l4c2_3x3d4": (4, 512, 128, 256, 512, 3, 1, 4, 4),
     "l4c3_1x1": (4, 512, 128, 256, 2048, 1, 1, 0, 1),
