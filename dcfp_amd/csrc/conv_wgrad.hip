@@ -519,52 +519,64 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         const int pq = kbeg - img0 * p.P;
         c_oh = pq / p.Wo; c_ow = pq - c_oh * p.Wo;
     }
-    auto issue = [&](int buf) {
+    // The copies of K-step kt+1 are issued in 8 pieces (4 instructions for dy, 4 for x), each with its branch-free
+    // address arithmetic, one piece behind every second MFMA of the step's first group, and the second half-step's
+    // fragments are read behind the first MFMA.  (Round 2: with everything at the top of the step - ~100 VALU /
+    // branch instructions and 16 LDS reads before the first MFMA - the kernel measured the same, 123..136 TF on
+    // the R101 shapes; profiles/r02_wgrad_issue_ab.txt.  The steady state is not issue-bound.)
+    auto issue_a = [&](int buf, auto q_) {
+        constexpr int q = decltype(q_)::value;
         // (uniform values; readfirstlane makes the compiler keep them in SGPRs for the asm operands)
         const unsigned a_s = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.dy_nstride + c_oh * p.dy_pitch + c_ow) * 4u);
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BM + 64 * wid + 16 * q) * BK) * 4u);
+        const unsigned av = a_voff[q], as_ = a_s;
+        const u32x4 ad = a_desc;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory", "m0");
+    };
+    auto issue_b = [&](int buf, auto q_) {
+        constexpr int q = decltype(q_)::value;
         const unsigned b_img = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.x_nstride) * 4u);
         const int oh = c_oh, ow = c_ow;
-        static_for<0, 4>([&](auto q_) {
-            constexpr int q = decltype(q_)::value;
-            const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BM + 64 * wid + 16 * q) * BK) * 4u);
-            const unsigned av = a_voff[q], as_ = a_s;
-            const u32x4 ad = a_desc;
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 16 * q) * BK) * 4u);
+        const int hh = oh + bq_dh[q], ww = ow + 4 * gq + bq_dw[q];
+        const bool row_ok = (unsigned)hh < (unsigned)p.H;
+        // pitched x: the quad may hang over a row end into the zero tail (of this or the previous row)
+        const bool ok = row_ok & ((unsigned)(ww + padx) <= (unsigned)(p.W + 2 * padx - 4));
+        const unsigned bs_ = b_img;
+        const u32x4 bd = b_desc;
+        bool quads = true;
+        if constexpr (MIXED)      // a quad that straddles the image border: only on a row's first / last K-step
+            quads = __ballot(row_ok && !ok && ww > -4 && ww < p.W) == 0;
+        if (quads) {             // 16-byte copies; with a shifted tap the source is only 4/8-byte aligned
+            const unsigned off = (unsigned)(bq_c[q] + hh * p.x_pitch + ww + padx) * 4u;
+            const unsigned bv = ok ? off : kOob;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(la), "v"(av), "s"(ad), "s"(as_) : "memory", "m0");
-        });
-        static_for<0, 4>([&](auto q_) {
-            constexpr int q = decltype(q_)::value;
-            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BN + 64 * wid + 16 * q) * BK) * 4u);
-            const int hh = oh + bq_dh[q], ww = ow + 4 * gq + bq_dw[q];
-            const bool row_ok = hh >= 0 && hh < p.H;
-            // pitched x: the quad may hang over a row end into the zero tail (of this or the previous row)
-            const bool ok = row_ok && ww >= -padx && ww + 3 < p.W + padx;
-            const unsigned bs_ = b_img;
-            const u32x4 bd = b_desc;
-            bool quads = true;
-            if constexpr (MIXED)      // a quad that straddles the image border: only on a row's first / last K-step
-                quads = __ballot(row_ok && !ok && ww > -4 && ww < p.W) == 0;
-            if (quads) {             // 16-byte copies; with a shifted tap the source is only 4/8-byte aligned
-                const unsigned bv = ok ? (unsigned)(bq_c[q] + hh * p.x_pitch + ww + padx) * 4u : kOob;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
-            } else if constexpr (MIXED) {
-                static_for<0, 4>([&](auto e_) {
-                    constexpr int e = decltype(e_)::value;
-                    constexpr int qe = 4 * q + e;
-                    const unsigned le = lb + (unsigned)(4 * e * BK) * 4u;
-                    const int h1 = oh + bd_dh[qe], w1 = ow + 4 * (gd ^ e) + (lane & 3) + bd_dw[qe];
-                    const bool ok1 = h1 >= 0 && h1 < p.H && w1 >= 0 && w1 < p.W;
-                    const unsigned bv = ok1 ? (unsigned)(bd_c[qe] + h1 * p.x_pitch + w1 + padx) * 4u : kOob;
-                    const unsigned bs2 = bs_;
-                    const u32x4 bd2 = bd;
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                                 :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory", "m0");
-                });
-            }
-        });
+                         :: "s"(lb), "v"(bv), "s"(bd), "s"(bs_) : "memory", "m0");
+        } else if constexpr (MIXED) {
+            static_for<0, 4>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                constexpr int qe = 4 * q + e;
+                const unsigned le = lb + (unsigned)(4 * e * BK) * 4u;
+                const int h1 = oh + bd_dh[qe], w1 = ow + 4 * (gd ^ e) + (lane & 3) + bd_dw[qe];
+                const bool ok1 = ((unsigned)h1 < (unsigned)p.H) & ((unsigned)w1 < (unsigned)p.W);
+                const unsigned off1 = (unsigned)(bd_c[qe] + h1 * p.x_pitch + w1 + padx) * 4u;
+                const unsigned bv = ok1 ? off1 : kOob;
+                const unsigned bs2 = bs_;
+                const u32x4 bd2 = bd;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                             :: "s"(le), "v"(bv), "s"(bd2), "s"(bs2) : "memory", "m0");
+            });
+        }
+    };
+    auto advance = [&]() {
         c_ow += BK;
         if (c_ow >= p.Wo) { c_ow = 0; if (++c_oh >= p.Ho) { c_oh = 0; ++c_im; } }
+    };
+    auto issue = [&](int buf) {
+        static_for<0, 4>([&](auto q_) { issue_a(buf, q_); });
+        static_for<0, 4>([&](auto q_) { issue_b(buf, q_); });
+        advance();
     };
     auto retire = [&]() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -589,31 +601,49 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     const int f0 = 4 * ((0 + lhi) ^ sw), f1 = 4 * ((2 + lhi) ^ sw);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) issue(cur ^ 1);
+        const bool more = kt + 1 < nk;
         const float* a = As + cur * (BM * BK) + a_row;
         const float* b = Bs + cur * (BN * BK) + b_row;
         f32x4 af[2][TM], bf[2][TN];
+        // the first half-step's fragments now, the second half's behind the first MFMA (they are needed 64 MFMAs on)
         static_for<0, TM>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             af[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK + f0);
-            af[1][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK + f1);
         });
         static_for<0, TN>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             bf[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * BK + f0);
-            bf[1][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * BK + f1);
         });
         static_for<0, 8>([&](auto s_) {
             constexpr int s = decltype(s_)::value;
             constexpr int kq = s / 4, e = s % 4;
             static_for<0, TM>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
-                if (!WIDE || i < nb) {
-                    static_for<0, TN>([&](auto j_) {
-                        constexpr int j = decltype(j_)::value;
+                static_for<0, TN>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    constexpr int n = i * TN + j;
+                    if (!WIDE || i < nb)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][i][e], bf[kq][j][e], acc[i][j], 0, 0, 0);
-                    });
-                }
+                    if constexpr (s == 0 && n == 0) {
+                        static_for<0, TM>([&](auto i2_) {
+                            constexpr int i2 = decltype(i2_)::value;
+                            af[1][i2] = *reinterpret_cast<const f32x4*>(a + i2 * 32 * BK + f1);
+                        });
+                        static_for<0, TN>([&](auto j2_) {
+                            constexpr int j2 = decltype(j2_)::value;
+                            bf[1][j2] = *reinterpret_cast<const f32x4*>(b + j2 * 32 * BK + f1);
+                        });
+                    }
+                    if constexpr (s == 0 && (n & 1) == 1) {      // piece n / 2 of the next step's copies
+                        if (more) {
+                            constexpr int piece = n / 2;
+                            if constexpr (piece < 4) issue_a(cur ^ 1, std::integral_constant<int, piece>{});
+                            else issue_b(cur ^ 1, std::integral_constant<int, piece - 4>{});
+                            if constexpr (piece == 7) advance();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
             });
             __builtin_amdgcn_sched_barrier(0);
         });
