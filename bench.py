@@ -153,6 +153,9 @@ def roofline_from_profile(recs, images_per_step, step_s):
     # bf16 MFMA peak / 6 in fp32-equivalent FLOP/s
     split = dom.startswith(("igemm3_kernel", "wgrad3_kernel"))
     peak = PEAK_BF16_MFMA / 6.0 if split else PEAK_F32_MFMA
+    wino = dom.startswith("winograd")
+    if wino:     # a Winograd op (two transform passes + batched GEMM): the MFMA work issued, not the direct-conv count
+        w_nominal, w = w, w_exec
     roof = {"bound": "mfma", "kernel": dom, "achieved": w / (ms * 1e-3) / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": w / (ms * 1e-3) / peak,
             # `achieved` counts the nominal multiply-adds of the convolutions (padded taps included - SURVEY 8d);
@@ -161,6 +164,10 @@ def roofline_from_profile(recs, images_per_step, step_s):
             "executed_frac": w_exec / (ms * 1e-3) / peak, "traffic": traffic,
             "traffic_note": traffic_note,
             "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "flop_per_launch": w / cnt,
+            **({"nominal_TFLOP/s": w_nominal / (ms * 1e-3) / 1e12,
+                "note": "Winograd F(2x2,3x3): achieved = MFMA FLOPs issued by the batched GEMM / time of the whole op "
+                        "(input transform + GEMM + output transform); nominal = direct-conv FLOP count / same time"}
+               if wino else {}),
             "dtype": "f32 as 3 bf16 planes (6 x v_mfma_f32_32x32x16_bf16 per product)" if split
                      else "f32 (v_mfma_f32_32x32x2_f32)"}
     others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "executed_TFLOP/s": v[3] / (v[1] * 1e-3) / 1e12,

@@ -55,7 +55,14 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale = nullptr, const float* shift = nullptr,
                     const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0,
-                    int in_pitch = 0);
+                    int in_pitch = 0, long long wp_nstride = 0);
+// conv_winograd.hip
+bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck);
+size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
+double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck);
+int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
+                  float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
+                  void* workspace, size_t workspace_bytes, hipStream_t stream);
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 bool dcfp_igemm2_persist();
@@ -84,8 +91,47 @@ static bool igemm3_ok(int M, long long px, int sn, int sd) {
     return math_bf16x3() && sn == 1 && sd == 1 && dcfp_igemm2_cfg_id(M, px, sd) == 4;
 }
 
+// Winograd F(2x2, 3x3) (conv_winograd.hip) takes a wide 3x3 stride-1 pad == dil conv, forward or dgrad, where a
+// cost model calibrated on this chip says it is faster than the direct LDS-DMA kernel (same-box measurements,
+// profiles/r02_winograd_ab.txt): direct = nominal FLOPs x executed share (dead kernel rows) at 143 TF; Winograd =
+// 16/36 of the nominal FLOPs x tile padding at 118 TF (K = 256) ... 135 TF (K >= 512) plus the two transform passes
+// at 4.2 / 5.4 TB/s.  DCFP_CONV_WINOGRAD: 0 off, 1 model (default), 2 wherever eligible (A/B).
+static bool wino_pass(const DcfpConvDesc* d, int pass) {
+    static const int mode = [] { const char* e = getenv("DCFP_CONV_WINOGRAD"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return false;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->Hout != d->H || d->Wout != d->W)
+        return false;
+    if (math_bf16x3()) return false;
+    const bool fwd = pass == DCFP_CONV_FWD;
+    const int M = fwd ? d->Cout : d->Cin, Ck = fwd ? d->Cin : d->Cout;
+    if (!dcfp_wino_ok(d->N, d->H, d->W, d->dil, M, Ck)) return false;
+    if (mode == 2) return true;
+    const int sp = fwd ? d->x_pitch : d->dy_pitch;
+    const bool pitched = sp && sp != d->W;
+    const double nominal = 2.0 * d->N * (double)d->H * d->W * (double)M * Ck * 9.0;
+    const double f_direct = fwd ? dcfp_igemm2_exec_fraction(9, M, Ck, d->N, d->H, d->W, d->H, d->W, 1, 1, -d->pad, d->dil, pitched)
+                                : dcfp_igemm2_exec_fraction(9, M, Ck, d->N, d->H, d->W, d->H, d->W, 1, 1, d->pad, -d->dil, pitched);
+    const double t_direct = nominal * f_direct / 143e12;
+    const double f_wino = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, M, Ck);
+    const double tiles = f_wino * 9.0 / 16.0 * d->N * (double)d->H * d->W;          // T
+    const double rate = Ck <= 256 ? 118e12 : Ck < 512 ? 126e12 : 135e12;
+    const double pix = (double)d->N * d->H * d->W;
+    const double t_in = (4.0 * pix * Ck + 64.0 * tiles * Ck) / 4.2e12;
+    const double t_out = (64.0 * tiles * M + 4.0 * pix * M * (fwd ? 1.0 : 2.0)) / 5.4e12;
+    const double t_wino = nominal * f_wino / rate + t_in + t_out + 20e-6;
+    return t_wino < 0.97 * t_direct;
+}
+
+extern "C" int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass) {
+    if (check_desc(d) != DCFP_OK || pass == DCFP_CONV_WGRAD) return 0;
+    return wino_pass(d, pass) ? 1 : 0;
+}
+
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK) return 0;
+    if (wino_pass(d, pass))
+        return pass == DCFP_CONV_FWD ? dcfp_wino_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)
+                                     : dcfp_wino_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cin, d->Cout);
     const int T = d->KH * d->KW;
     size_t b2, b3 = 0;
     if (pass == DCFP_CONV_FWD) {
@@ -105,6 +151,7 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     if (rc) return rc;
     if (!buf || buf_len <= 0) return DCFP_E_BADDESC;
     if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_kernel_name(d, buf, buf_len);
+    if (wino_pass(d, pass)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 (igemm2_dma1p_kernel<false,true>)");
     const int M = pass == DCFP_CONV_FWD ? d->Cout : d->Cin;
     const long long px = pass == DCFP_CONV_FWD ? (long long)d->N * d->Hout * d->Wout : (long long)d->N * d->H * d->W;
     const int sd = pass == DCFP_CONV_FWD ? 1 : d->stride;
@@ -136,6 +183,9 @@ extern "C" double dcfp_conv2d_executed_fraction(const DcfpConvDesc* d, int pass)
     if (check_desc(d) != DCFP_OK) return 1.0;
     if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_exec_fraction(d);
     const bool fwd = pass == DCFP_CONV_FWD;
+    if (wino_pass(d, pass))
+        return fwd ? dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)
+                   : dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cin, d->Cout);
     const int M = fwd ? d->Cout : d->Cin;
     const long long px = fwd ? (long long)d->N * d->Hout * d->Wout : (long long)d->N * d->H * d->W;
     if (igemm3_ok(M, px, fwd ? d->stride : 1, fwd ? 1 : d->stride)) return 1.0;
@@ -156,6 +206,10 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     if (!x || !w || !y) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
     if (d->x_pitch && d->x_pitch != d->W && math_bf16x3()) return DCFP_E_UNSUPPORTED;
+    if (!bias && wino_pass(d, DCFP_CONV_FWD))
+        return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T,
+                             0, y, y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout,
+                             d->Cin, d->H, d->W, d->dil, 0, workspace, workspace_bytes, dcfp_s(stream));
     if (!bias && igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                                y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
@@ -172,6 +226,7 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
 // dcfp_bn_stats_from_partials_f32).  slots == 0: this shape / math mode has no fused statistics.
 extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride) {
     if (check_desc(d) != DCFP_OK) return 0;
+    if (wino_pass(d, DCFP_CONV_FWD)) return 0;      // (the output transform has no statistics epilogue)
     if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1)) return 0;
     return dcfp_igemm2_stat_slots(d->Cout, d->Hout * d->Wout, d->N,
                                   y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, y);
@@ -202,6 +257,10 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (!dy || !w || !dx) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
     if (d->dy_pitch && d->dy_pitch != d->Wout && math_bf16x3()) return DCFP_E_UNSUPPORTED;
+    if (wino_pass(d, DCFP_CONV_DGRAD))      // dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees
+        return dcfp_wino_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * (d->dy_pitch ? d->dy_pitch : d->Wout),
+                             d->dy_pitch, w, T, d->Cin * T, 1, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin, d->Cout,
+                             d->H, d->W, d->dil, accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream));
     if (igemm3_ok(d->Cin, (long long)d->N * d->H * d->W, 1, d->stride))
         return dcfp_igemm3_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
                                T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,

@@ -1153,11 +1153,12 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale, const float* shift, const float* residual, int relu,
-                    float* stat_part, int wp_valid, int in_pitch) {
+                    float* stat_part, int wp_valid, int in_pitch, long long wp_nstride) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
     p.stat_part = stat_part;
+    p.wp_nstride = wp_nstride;
     p.in = in; p.bias = bias; p.out = out;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
@@ -1213,7 +1214,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                            Ck, p.CkP, M, p.Mpad, sAm, sAc, d8 ? 1 : 0);
     }
     if (d8) {
-        if (!p.vec_store) return DCFP_E_UNSUPPORTED;
+        if (!p.vec_store || wp_nstride) return DCFP_E_UNSUPPORTED;
         return dcfp_igemm2n_launch(p, T, stream);
     }
     if (dcfp_igemm2_dma_shape(T, M, Ck, p.P, px, sn, sd, off0, Hi * Wi, Wo) && p.vec_store && !bias && !scale &&
@@ -1231,11 +1232,15 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         };
         if (T == 1) {
             if (dcfp_igemm2_persist()) return dcfp_igemm2p_launch(p, stream);
+            if (wp_nstride) return DCFP_E_UNSUPPORTED;
             return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
         }
         if (((off0 | offstep) & 3) == 0 || pitched)    // pitched rows: shifted quads need no border handling
             return accumulate ? launch(igemm2_dma_kernel<9, false, true>) : launch(igemm2_dma_kernel<9, false, false>);
         return accumulate ? launch(igemm2_dma_kernel<9, true, true>) : launch(igemm2_dma_kernel<9, true, false>);
     }
+    if (wp_nstride) return DCFP_E_UNSUPPORTED;     // per-image weights exist on the persistent 1x1 kernel only
     return T == 1 ? launch_taps<1>(p, c.id, stream) : launch_taps<9>(p, c.id, stream);
 }
+
+int dcfp_igemm2_ck_pad() { return ck_pad(); }

@@ -44,7 +44,9 @@ __device__ __forceinline__ u32x4 make_desc(const void* base, unsigned bytes) {  
 
 constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, M2) pairs
 
-template <bool ACC>
+// WPI: every image has its own weight copy (p.wp_nstride floats apart) - the batched GEMM of conv_winograd.hip,
+// a kernel instance of its own so that profiles tell it from the 1x1 convs
+template <bool ACC, bool WPI = false>
 __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles, int dbg) {
     constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
         decode(ld_tile, nt, mt);
         const int img = nt / p.tiles_per_img;
         const int p0 = (nt - img * p.tiles_per_img) * BN;
-        ld_as = (unsigned)(mt * BM) * 4u;
+        ld_as = (unsigned)(mt * BM + (WPI ? img * (int)p.wp_nstride : 0)) * 4u;
         ld_bdesc = make_desc(p.in + (long long)img * p.in_nstride, (unsigned)(p.Ck * HiWi) * 4u);
         const int pp = p0 + 4 * lane;                 // P % 4 == 0: a quad is inside or outside as a whole
         ld_boff4 = pp < p.P ? (unsigned)pp * 4u : kOob;
@@ -330,5 +332,9 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, (int)total, dbg);
         DCFP_RETURN_LAUNCH();
     };
+    if (p.wp_nstride) {
+        if (p.accumulate) return DCFP_E_UNSUPPORTED;
+        return launch(igemm2_dma1p_kernel<false, true>);
+    }
     return p.accumulate ? launch(igemm2_dma1p_kernel<true>) : launch(igemm2_dma1p_kernel<false>);
 }

@@ -1,0 +1,239 @@
+// conv_winograd.hip — Winograd F(2x2, 3x3) for the wide 3x3 stride-1 convs (pad == dilation), forward and dgrad
+// (networks/backbone/resnet.py:27-28 layer3/layer4 conv2, networks/tools/aspp.py:37-39, networks/deeplabv3.py:25-41).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        per 4x4 input patch d -> 2x2 outputs, 16 products instead of 36
+//
+// fp32 throughout: the multiplicands are fp32 sums / half-sums of fp32 values and go through the same
+// v_mfma_f32_32x32x2_f32 as the direct kernels (this is an algebraic restructuring, not a narrower number format;
+// cuDNN / MIOpen pick the same algorithm for fp32 3x3 convs).  Three memory-bound passes around ONE batched GEMM:
+//   1. wino_input_kernel   x[N][C][H][W]            -> V[16][C][T]      (B^T d B, adds only)
+//   2. igemm2_dma1p_kernel  M[xi] = U[xi] * V[xi]   for xi = 0..15: the persistent 1x1 LDS-DMA kernel of
+//                           conv_igemm2p.hip with "16 images" whose weights differ per image (wp_nstride)
+//   3. wino_output_kernel  M[16][K][T]              -> y[N][K][H][W]    (A^T m A, adds only; += for the dgrad fan-in)
+// and wino_filter_kernel   w -> U[16][CkP][Mpad]    (G g G^T; rebuilt per call: <= 34 MB, ~10 us).
+//
+// Dilation d: the image is cut into super-blocks of 2d x 2d pixels; tile (a, b) of a super-block owns the outputs
+// at rows {a, a + d} x columns {b, b + d} and reads rows a - d, a, a + d, a + 2d (same for columns) - the 3x3 conv
+// with dilation d restricted to the residue class (a, b) mod d is an undilated conv.  Tile column index
+// tcol = j * d + b, so that consecutive tiles read / write consecutive pixels (runs of d).
+#include "igemm2_common.h"
+
+int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int sAm, int sAc,
+                    const float* bias, float* out, long long out_nstride, int N, int M, int Ck, int T,
+                    int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
+                    int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                    const float* scale, const float* shift, const float* residual, int relu, float* stat_part,
+                    int wp_valid, int in_pitch, long long wp_nstride);
+bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
+bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
+                          int Wo, bool pitched);
+bool dcfp_igemm2_persist();
+int dcfp_igemm2_ck_pad();
+
+namespace {
+
+inline long long align64(long long v) { return (v + 63) / 64 * 64; }   // floats: 256-byte sections
+
+struct WinoPlan {
+    int TH, TW;           // tiles per image (rows, columns)
+    long long T;          // tiles over the batch = GEMM pixels per transformed component
+    int CkP, Mpad;
+    long long u_floats, v_floats, m_floats;
+};
+
+WinoPlan wino_plan(int N, int H, int W, int d, int M, int Ck) {
+    WinoPlan pl;
+    pl.TH = d * ((H + 2 * d - 1) / (2 * d));
+    pl.TW = d * ((W + 2 * d - 1) / (2 * d));
+    pl.TW = (pl.TW + 3) / 4 * 4;                  // GEMM rows of 16-byte quads (the extra tiles have no outputs)
+    pl.T = (long long)N * pl.TH * pl.TW;
+    pl.CkP = (Ck + dcfp_igemm2_ck_pad() - 1) / dcfp_igemm2_ck_pad() * dcfp_igemm2_ck_pad();
+    pl.Mpad = (M + 255) / 256 * 256;
+    pl.u_floats = align64(16LL * pl.CkP * pl.Mpad);
+    pl.v_floats = align64(16LL * Ck * pl.T);
+    pl.m_floats = align64(16LL * M * pl.T);
+    return pl;
+}
+
+// U[xi][c][m] = (G g G^T)[xi],  g[kh][kw] = w[m * sAm + c * sAc + tap],  tap = kh*3+kw (flip: 8 - tap: dgrad)
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, int sAm, int sAc, int flip,
+                                                          int M, int Ck, int CkP, int Mpad, float* __restrict__ U) {
+    const long long plane = (long long)CkP * Mpad;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < plane; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx / Mpad), m = (int)(idx - (long long)c * Mpad);
+        float g[9];
+        if (m < M && c < Ck) {
+            const float* src = w + (long long)m * sAm + (long long)c * sAc;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g[t] = src[flip ? 8 - t : t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g[t] = 0.f;
+        }
+        // rows: G g  (4 x 3)
+        float r[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
+            r[0][k] = g0;
+            r[1][k] = 0.5f * ((g0 + g2) + g1);
+            r[2][k] = 0.5f * ((g0 + g2) - g1);
+            r[3][k] = g2;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = r[i][0], b = r[i][1], cc = r[i][2];
+            U[(4 * i + 0) * plane + idx] = a;
+            U[(4 * i + 1) * plane + idx] = 0.5f * ((a + cc) + b);
+            U[(4 * i + 2) * plane + idx] = 0.5f * ((a + cc) - b);
+            U[(4 * i + 3) * plane + idx] = cc;
+        }
+    }
+}
+
+// V[xi][c][n * TH * TW + t] = (B^T d B)[xi] of tile t of image n, channel c.  grid (ceil(TH*TW / 256), N, C).
+// One tile per thread, 16 scalar loads (consecutive tiles read consecutive pixels in runs of d; the four tiles that
+// share an input element find it in L1 / L2), 16 coalesced stores.  (A version that staged the strip's four input
+// rows in LDS with coalesced loads measured 4...19 % slower per conv: one barrier per 128 tiles, half the threads idle.)
+__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, long long x_nstride, int pitch,
+                                                         int C, int H, int W, int d, int TH, int TW,
+                                                         float* __restrict__ V, long long T) {
+    const int tpi = TH * TW;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tpi) return;
+    const int n = blockIdx.y, c = blockIdx.z;
+    const int trow = t / TW, tcol = t - trow * TW;
+    const int h0 = trow + d * (trow / d) - d, w0 = tcol + d * (tcol / d) - d;
+    const float* src = x + (long long)n * x_nstride + (long long)c * H * pitch;
+    float p[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = h0 + r * d;
+        const bool hok = (unsigned)h < (unsigned)H;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ww = w0 + s * d;
+            p[r][s] = (hok && (unsigned)ww < (unsigned)W) ? src[(long long)h * pitch + ww] : 0.f;
+        }
+    }
+    // B^T p: rows
+    float q[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        q[0][s] = p[0][s] - p[2][s];
+        q[1][s] = p[1][s] + p[2][s];
+        q[2][s] = p[2][s] - p[1][s];
+        q[3][s] = p[1][s] - p[3][s];
+    }
+    const long long plane = (long long)C * T;
+    float* dst = V + (long long)c * T + (long long)n * tpi + t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dst[(4 * r + 0) * plane] = q[r][0] - q[r][2];
+        dst[(4 * r + 1) * plane] = q[r][1] + q[r][2];
+        dst[(4 * r + 2) * plane] = q[r][2] - q[r][1];
+        dst[(4 * r + 3) * plane] = q[r][1] - q[r][3];
+    }
+}
+
+// y[n][k][2x2 outputs of tile t] (+)= A^T m A,  m[xi] = Mb[xi][k][n * TH * TW + t].  grid (ceil(TH*TW / 256), N, K)
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mb, long long T, int K,
+                                                          float* __restrict__ y, long long y_nstride, int H, int W,
+                                                          int d, int TH, int TW, int accumulate) {
+    const int tpi = TH * TW;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tpi) return;
+    const int n = blockIdx.y, k = blockIdx.z;
+    const int trow = t / TW, tcol = t - trow * TW;
+    const int ho = trow + d * (trow / d), wo = tcol + d * (tcol / d);
+    if (ho >= H || wo >= W) return;
+    const long long plane = (long long)K * T;
+    const float* src = Mb + (long long)k * T + (long long)n * tpi + t;
+    float m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) m[r][s] = src[(4 * r + s) * plane];
+    // A^T m: rows   A^T = [1 1 1 0; 0 1 -1 -1]
+    float u[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u[0][s] = (m[0][s] + m[1][s]) + m[2][s];
+        u[1][s] = (m[1][s] - m[2][s]) - m[3][s];
+    }
+    float o[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        o[r][0] = (u[r][0] + u[r][1]) + u[r][2];
+        o[r][1] = (u[r][1] - u[r][2]) - u[r][3];
+    }
+    float* dst = y + (long long)n * y_nstride + (long long)k * H * W;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int h = ho + r * d;
+        if (h >= H) continue;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ww = wo + s * d;
+            if (ww >= W) continue;
+            float* e = dst + (long long)h * W + ww;
+            *e = accumulate ? *e + o[r][s] : o[r][s];
+        }
+    }
+}
+
+}  // namespace
+
+// 3x3, stride 1, pad == dil, same-size output; M = output channels of the pass, Ck = reduced channels
+bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck) {
+    if (!dcfp_igemm2_persist()) return false;
+    if (M < 256 || Ck < 256) return false;                       // the transforms cost ~ 1/M + 1/Ck of the GEMM
+    const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
+    if (4 * pl.T > (long long)N * H * W * 27 / 20) return false;  // > 35 % padding of the 2d x 2d super-blocks
+    if (pl.T >= (1LL << 26) || 16LL * pl.T >= (1LL << 30)) return false;
+    if ((long long)Ck * pl.T >= (1LL << 29) || (long long)M * pl.T >= (1LL << 29)) return false;
+    const int P = (int)pl.T;
+    if (dcfp_igemm2_use_dma8(1, M, P, 16LL * P, 1, 1, 0, 1, P, pl.TW, false)) return false;
+    return dcfp_igemm2_dma_shape(1, M, Ck, P, 16LL * P, 1, 1, 0, P, pl.TW);
+}
+
+size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck) {
+    const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
+    return (size_t)(pl.u_floats + pl.v_floats + pl.m_floats) * sizeof(float);
+}
+
+// share of the nominal multiply-adds (2*N*M*H*W*Ck*9) that the batched GEMM issues
+double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck) {
+    const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
+    return 16.0 * (double)pl.T / (9.0 * (double)N * H * W);
+}
+
+// in: x (forward) or dy (dgrad), rows at `in_pitch` floats; w with strides (sAm, sAc) as dcfp_igemm2_run takes them
+int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
+                  float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
+                  void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
+    if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
+        return DCFP_E_WORKSPACE;
+    float* U = static_cast<float*>(workspace);
+    float* V = U + pl.u_floats;
+    float* Mb = V + pl.v_floats;
+    {
+        long long b = ((long long)pl.CkP * pl.Mpad + 255) / 256;
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, sAm, sAc, flip, M, Ck,
+                           pl.CkP, pl.Mpad, U);
+    }
+    const int tpi = pl.TH * pl.TW;
+    if (Ck > 65535 || M > 65535 || N > 65535) return DCFP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((tpi + 255) / 256), (unsigned)N, (unsigned)Ck), dim3(256), 0,
+                       stream, in, in_nstride, in_pitch > 0 ? in_pitch : W, Ck, H, W, d, pl.TH, pl.TW, V, pl.T);
+    const int rc = dcfp_igemm2_run(V, (long long)Ck * pl.T, nullptr, 0, 0, nullptr, Mb, (long long)M * pl.T, 16, M, Ck, 1,
+                                   N * pl.TH, pl.TW, N * pl.TH, pl.TW, 1, 1, 0, 1, 0, U,
+                                   (size_t)pl.u_floats * sizeof(float), stream, nullptr, nullptr, nullptr, 0, nullptr,
+                                   /*wp_valid=*/1, 0, (long long)pl.CkP * pl.Mpad);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((tpi + 255) / 256), (unsigned)N, (unsigned)M), dim3(256), 0,
+                       stream, Mb, pl.T, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate);
+    DCFP_RETURN_LAUNCH();
+}

@@ -24,6 +24,8 @@ struct Igemm2Params {
     int in_pitch;       // row pitch (floats) of the B source; > Wi: rows carry a zero tail of in_pitch - Wi floats, so a
                         // shifted 16-byte quad may hang over either row end and still read zeros (no border handling)
     int zfold;          // strided dgrad of a 1x1 conv: only phase `zfold - 1` has a tap; its tiles also write the zeros
+    long long wp_nstride;   // igemm2_dma1p_kernel: floats between the weight copies of consecutive images (0: shared) - the
+                            // batched GEMM of conv_winograd.hip, where "image" xi has its own transformed filter
     int tapskip;        // 9-tap LDS-DMA kernels: K-steps of kernel rows that lie wholly in the padding for a tile are skipped
     float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
 };

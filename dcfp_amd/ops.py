@@ -233,6 +233,16 @@ def _wp_buffer(w, which, d, nbytes, variant=""):
     return buf, 0
 
 
+def _conv_workspace(w, which, d):
+    """(workspace, wp_valid) of a forward / dgrad call: the conv's own persistent Wp buffer, or - where the library
+    says the workspace is pure scratch (Winograd: transformed operands, hundreds of MB) - one buffer shared by all."""
+    L = _lib.lib()
+    nbytes = L.dcfp_conv2d_workspace_bytes(C.byref(d), which)
+    if L.dcfp_conv2d_workspace_is_scratch(C.byref(d), which):
+        return _workspace("conv_scratch", nbytes, w.device), 0
+    return _wp_buffer(w, which, d, nbytes)
+
+
 def refresh_wp():
     """After an in-place weight update: rebuild every registered Wp copy with one launch and mark them valid
     for the current WEIGHT_EPOCH.  The device table of (weights, copy, layout) records is rebuilt only when
@@ -318,7 +328,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run
     if bias is not None:
         _require(bias, "bias"); bias = bias.contiguous()
     L = _lib.lib()
-    ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD))
+    ws, valid = _conv_workspace(w, _lib.CONV_FWD, d)
     if want_stats and bias is None:
         slots = L.dcfp_conv2d_fwd_stat_slots(C.byref(d), _p(y), yns)
         if slots > 0:
@@ -354,7 +364,7 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
         dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
         accumulate = False
     L = _lib.lib()
-    ws, valid = _wp_buffer(w, _lib.CONV_DGRAD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_DGRAD))
+    ws, valid = _conv_workspace(w, _lib.CONV_DGRAD, d)
     _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
         L.dcfp_conv2d_dgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), int(bool(accumulate)),
                                      _p(ws), ws.numel(), valid, _stream()), "conv2d_dgrad"))

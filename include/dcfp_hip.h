@@ -101,6 +101,12 @@ int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, int n_entrie
  * (x_pitch / dy_pitch > 0): 3x3, stride 1, pad = dil, the 256 x 256 LDS-DMA tiles; else 0. */
 int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d);
 
+/* 1 when the pass's workspace is pure scratch (the Winograd path of conv_winograd.hip: transformed filters,
+ * transformed input and the batched GEMM's output - up to a few GB for the ASPP branches): nothing in it survives
+ * the call, `wp_valid` is ignored, and a caller should hand every such conv the SAME buffer instead of keeping one
+ * per conv.  0: the workspace holds the permuted weight copy described under `wp_valid`. */
+int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass);
+
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
  * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the
  * string rocprofv3 shows (demangled) for the launch; used by bench.py to label rooflines.

@@ -11,6 +11,8 @@ properties instead: (a) the step is bit-reproducible (every reduction has a fixe
 bit for bit in fp32) on the model's FLOP-dominant shapes, (c) accumulate-dgrad == plain dgrad +
 seed, (d) the per-rank mean-of-valid-pixels loss is invariant to relabelling ignored pixels.
 Tolerances: SURVEY.md Appendix D (loss 1e-5 relative, gradients rel-L2 5e-2, logits 1e-3)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +21,7 @@ from oracle import fill, model as omodel
 from oracle.train_step import CpuTrainer
 
 pytestmark = pytest.mark.gpu
+WINO = os.environ.get("DCFP_CONV_WINOGRAD", "1") != "0"
 BB = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
 
 
@@ -209,7 +212,8 @@ def test_config3_dgrad_wgrad_vs_fp64_slice(cuda, shape, kernels):
     desc = ops._desc(x.shape, w.shape, s, p, d)
     for want, which in zip(kernels, (_lib.CONV_DGRAD, _lib.CONV_WGRAD)):
         if want is not None:
-            assert ops.conv_kernel_name(desc, which) == want, (ops.conv_kernel_name(desc, which), want)
+            name = ops.conv_kernel_name(desc, which)      # (Winograd unless DCFP_CONV_WINOGRAD=0: test_winograd_gpu.py)
+            assert name == want or (WINO and name.startswith("winograd_f2x2_3x3")), (name, want)
     Ho, Wo = desc.Hout, desc.Wout
     dy = (torch.randn(N, Cout, Ho, Wo, generator=g) * 1e-2).to(cuda)
     dx = ops.conv2d_dgrad(dy, w, tuple(x.shape), s, p, d)

@@ -1,0 +1,128 @@
+"""Winograd F(2x2, 3x3) path (dcfp_amd/csrc/conv_winograd.hip) for the wide 3x3 stride-1 convs
+(networks/backbone/resnet.py:27-28, networks/tools/aspp.py:37-39, networks/deeplabv3.py:25-41): forward and dgrad
+against fp64 on the CPU, next to the direct LDS-DMA kernels on the same inputs (the library reads
+DCFP_CONV_WINOGRAD once per process: 0 = direct kernels, 1 = cost model (default), 2 = wherever eligible; hence
+child processes), and the direct-kernel test files once more with the switch off, so that both algorithms stay
+covered whichever one the dispatcher prefers for a shape."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (N, Cin, H, W, Cout, dilation): even / odd sizes against the 2d x 2d super-blocks, every dilation of the model,
+# column counts whose tile rows need padding to 16-byte quads, one shape per GEMM regime (K = 256 / >= 512)
+SHAPES = [(2, 256, 64, 128, 256, 2), (4, 256, 50, 68, 512, 1), (5, 288, 33, 60, 256, 4), (2, 512, 64, 128, 256, 12),
+          (1, 256, 96, 192, 512, 24), (2, 256, 47, 129, 256, 2)]
+
+
+def _child():
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.nn.functional as F
+    from dcfp_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    out = {}
+    for (N, Cin, H, W, Cout, d) in SHAPES:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        x = torch.relu(x) + 0.05 * x                                     # post-ReLU-like statistics
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        dy = torch.randn(N, Cout, H, W, generator=g)
+        seed = torch.randn(N, Cin, H, W, generator=g)
+        xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+        desc = ops._desc(x.shape, w.shape, 1, d, d)
+        names = [ops.conv_kernel_name(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD)]
+        y = ops.conv2d_fwd(xd, wd, None, 1, d, d)
+        # forward into a channel slice of a wider tensor (the ASPP concat, aspp.py:77)
+        wide = torch.full((N, Cout + 64, H, W), 7.0, device=dev)
+        ops.conv2d_fwd(xd, wd, None, 1, d, d, out=wide[:, 32:32 + Cout])
+        dx = ops.conv2d_dgrad(dyd, wd, tuple(x.shape), 1, d, d)
+        acc = seed.to(dev).clone()
+        ops.conv2d_dgrad(dyd, wd, tuple(x.shape), 1, d, d, out=acc, accumulate=True)
+        # dgrad of a channel slice of a wider gradient (the ASPP backward reads its branch's slice in place)
+        dwide = torch.randn(N, Cout + 64, H, W, generator=g).to(dev)
+        dwide[:, 32:32 + Cout] = dyd
+        dx_slice = ops.conv2d_dgrad(dwide[:, 32:32 + Cout], wd, tuple(x.shape), 1, d, d)
+        rec = {"kernels": names, "slice_equal": bool(torch.equal(wide[:, 32:32 + Cout], y)),
+               "slice_untouched": bool((wide[:, :32] == 7.0).all() and (wide[:, 32 + Cout:] == 7.0).all()),
+               "dgrad_slice_equal": bool(torch.equal(dx_slice, dx)),
+               "frac": [ops.conv_executed_fraction(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD)],
+               "scratch": [int(_lib.lib().dcfp_conv2d_workspace_is_scratch(ops.C.byref(desc), k))
+                           for k in (_lib.CONV_FWD, _lib.CONV_DGRAD)]}
+        # row-pitched operands (zero tail behind each row) where the conv takes them
+        pitch = ops.conv_pitch(tuple(x.shape), tuple(w.shape), 1, d, d)
+        if pitch:
+            xp = ops.pitched_buffer(tuple(x.shape), pitch, "t_x", dev); xp.copy_(xd)
+            dyp = ops.pitched_buffer(tuple(dy.shape), pitch, "t_dy", dev); dyp.copy_(dyd)
+            rec["pitched_equal"] = bool(torch.equal(ops.conv2d_fwd(xp, wd, None, 1, d, d), y) and
+                                        torch.equal(ops.conv2d_dgrad(dyp, wd, tuple(x.shape), 1, d, d), dx))
+        torch.cuda.synchronize()
+        ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+        refdx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
+
+        def emax(a, b):
+            return float((a.cpu().double() - b).abs().max() / b.abs().max())
+
+        def erel(a, b):
+            return float((a.cpu().double() - b).norm() / b.norm())
+        rec.update(fwd_max=emax(y, ref), fwd_rel=erel(y, ref), dgrad_max=emax(dx, refdx), dgrad_rel=erel(dx, refdx),
+                   acc_max=emax(acc, refdx + seed.double()))
+        out[f"{N}x{Cin}x{H}x{W}->{Cout} d{d}"] = rec
+    print("WINO_RESULT " + json.dumps(out))
+
+
+def _run(mode):
+    env = dict(os.environ, DCFP_CONV_WINOGRAD=mode, DCFP_CONV_MATH="f32")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("WINO_RESULT ")][-1]
+    return json.loads(line[len("WINO_RESULT "):])
+
+
+def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
+    wino, direct = _run("2"), _run("0")
+    assert wino.keys() == direct.keys() and len(wino) == len(SHAPES)
+    for k, rec in wino.items():
+        ref = direct[k]
+        # (a pass whose output-channel count is off the 256 grid stays on the ragged-M direct kernel: 288-channel dgrad)
+        want = [True, int(k.split("x")[1]) % 256 == 0]
+        assert [n.startswith("winograd_f2x2_3x3") for n in rec["kernels"]] == want, (k, rec["kernels"])
+        assert not any(n.startswith("winograd") for n in ref["kernels"]), (k, ref["kernels"])
+        assert rec["scratch"] == [int(v) for v in want] and ref["scratch"] == [0, 0]
+        assert all(0.44 <= f <= 0.60 for f, v in zip(rec["frac"], want) if v), (k, rec["frac"])   # 16/36 x tile padding
+        assert rec["slice_equal"] and rec["slice_untouched"] and rec["dgrad_slice_equal"], (k, rec)
+        assert rec.get("pitched_equal", True), k
+        # the stated fp32 tolerance of the conv tests (tests/test_ops_gpu.py: 3e-6 * max(1, sqrt(K) / 8), K = 9 Cin) ...
+        K = 9 * int(k.split("x")[1])
+        tol = 3e-6 * max(1.0, math.sqrt(K) / 8)
+        for f in ("fwd_max", "dgrad_max", "acc_max"):
+            assert rec[f] < tol, (k, f, rec[f], tol)
+        # ... and no less accurate than the direct kernels (one K = 9 Cin accumulation chain there, 16 chains of
+        # length Cin plus 24 additions per output here): relative error within 1.25x of theirs
+        assert rec["fwd_rel"] <= 1.25 * ref["fwd_rel"] + 1e-8, (k, rec["fwd_rel"], ref["fwd_rel"])
+        assert rec["dgrad_rel"] <= 1.25 * ref["dgrad_rel"] + 1e-8, (k, rec["dgrad_rel"], ref["dgrad_rel"])
+
+
+def test_direct_conv_kernels_still_covered_with_winograd_off(cuda):
+    """The direct 9-tap kernels keep their shapes in the model (dilation-36 forward, channel counts below 256,
+    pruned widths, DCFP_CONV_WINOGRAD=0): their test files and the whole-model golden test run once more with the
+    switch off (kernel-name assertions there follow the switch)."""
+    env = dict(os.environ, DCFP_CONV_WINOGRAD="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+                        os.path.join(ROOT, "tests", "test_conv_large_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_fullsize_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_model_gpu.py"),
+                        "-k", "not bf16x3"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout
+
+
+if __name__ == "__main__" and "--child" in sys.argv:
+    _child()
