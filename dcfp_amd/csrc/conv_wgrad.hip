@@ -43,6 +43,8 @@ struct WgradParams {
     int kchunk, splits, tiles_m, tiles_n;
     int quad_ok;  // Wo % 4 == 0: the 4 pixels of a quad share (img, oh)
     int x_pitch, dy_pitch;   // row pitches (floats) of x / dy; > W / Wo: rows carry a zero tail (wgrad_dma_kernel only)
+    int batch;               // wgrad_dma_kernel<1>: independent problems in one launch (Winograd: 16 transformed components),
+    long long dy_bstride, x_bstride;   // floats between their operands; outputs [split][batch][M][Nn]
 };
 
 constexpr unsigned kOob = 0x80000000u;      // > any record count: buffer loads return 0
@@ -439,11 +441,16 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     float* As = smem;                   // [2][BM][BK]
     float* Bs = smem + 2 * BM * BK;     // [2][BN][BK]
     const int tiles = p.tiles_m * p.tiles_n;
-    int split, tile;
+    int split, tile, bi = 0;
     {
         const int full = (p.splits / 8) * 8;
         const int gsz = 8 * tiles;
-        const int b = blockIdx.x;
+        int b = blockIdx.x;
+        if (p.batch > 1) {             // problem-major: the workgroups of one problem share its operands in L2
+            const int per = tiles * p.splits;
+            bi = b / per;
+            b -= bi * per;
+        }
         if (b < (full / 8) * gsz) {
             const int g = b / gsz, r = b - g * gsz;
             tile = r >> 3;
@@ -477,10 +484,10 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         u32x4 d = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, kMaxRecords, 0x00020000u};
         return d;
     };
-    const u32x4 a_desc = make_desc(p.dy + (long long)img0 * p.dy_nstride);
+    const u32x4 a_desc = make_desc(p.dy + (long long)img0 * p.dy_nstride + (long long)bi * p.dy_bstride);
     // pitched x: offsets are taken from padx floats before the image (readable zeros by contract), so that a quad
     // hanging over the left end of the very first row keeps a non-negative offset
-    const u32x4 b_desc = make_desc(p.x + (long long)img0 * p.x_nstride - padx);
+    const u32x4 b_desc = make_desc(p.x + (long long)img0 * p.x_nstride + (long long)bi * p.x_bstride - padx);
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
 
     // ---- A (dy): instruction q of this wave copies rows 64*wid + 16q + (lane >> 2); the lane's slot
@@ -650,7 +657,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         retire();
     }
 
-    float* o = p.out + (long long)split * p.M * p.Nn;
+    float* o = p.out + ((long long)split * p.batch + bi) * p.M * p.Nn;
     int ncol = n0 + wn * (TN * 32) + l31;
     asm volatile("" : "+v"(ncol));
 #pragma unroll
@@ -838,7 +845,75 @@ bool dcfp_wgrad_pitch_ok(const DcfpConvDesc* d) {
     return true;
 }
 
+// `batch` independent products  out[b][m][c] = sum_t a[b][m][t] * bmat[b][c][t]  (t < K, K % 16 == 0, rows K floats
+// apart) in ONE launch of the LDS-DMA 1x1 weight-gradient kernel - the 16 transformed components of a Winograd
+// weight gradient (conv_winograd.hip).  workspace: split-K slabs [splits][batch][M][C] when splits > 1.
+size_t dcfp_wgrad_batched_workspace_bytes(int batch, int M, int C, long long K, int* splits_out) {
+    const long long tiles = (long long)((M + 255) / 256) * ((C + 255) / 256) * batch;
+    const long long slots = num_cus();
+    long long max_splits = K / (BK * 8);
+    if (max_splits < 1) max_splits = 1;
+    long long splits = 1;
+    double best = -1.0;
+    for (long long sp = 1; sp <= max_splits && tiles * sp <= 4 * slots; ++sp) {
+        const long long blocks = tiles * sp, rounds = (blocks + slots - 1) / slots;
+        double eff = (double)blocks / (double)(rounds * slots);
+        if (blocks < slots) eff *= 0.999;
+        if (eff > best + 0.02) { best = eff; splits = sp; }
+    }
+    long long kchunk = (K + splits - 1) / splits;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    splits = (K + kchunk - 1) / kchunk;
+    if (splits_out) *splits_out = (int)splits;
+    return splits > 1 ? (size_t)splits * batch * M * C * sizeof(float) : 0;
+}
+
+int dcfp_wgrad_batched_run(const float* a, const float* bmat, float* out, int batch, int M, int C, long long K,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (K % BK != 0 || K <= 0 || K >= (1LL << 30) || (long long)M * K >= (1LL << 29) || (long long)C * K >= (1LL << 29))
+        return DCFP_E_UNSUPPORTED;
+    int splits = 1;
+    const size_t need = dcfp_wgrad_batched_workspace_bytes(batch, M, C, K, &splits);
+    if (need && (!workspace || workspace_bytes < need || !dcfp_aligned16(workspace))) return DCFP_E_WORKSPACE;
+    WgradParams p;
+    p.dy = a; p.x = bmat;
+    p.out = splits > 1 ? static_cast<float*>(workspace) : out;
+    p.x_pitch = (int)K; p.dy_pitch = (int)K;
+    p.dy_nstride = (long long)M * K; p.x_nstride = (long long)C * K;
+    p.N = 1; p.M = M; p.Cin = C; p.Nn = C;
+    p.H = 1; p.W = (int)K; p.Ho = 1; p.Wo = (int)K; p.P = (int)K;
+    p.stride = 1; p.pad = 0; p.dil = 1;
+    p.Kpix = (int)K;
+    long long kchunk = (K + splits - 1) / splits;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    p.kchunk = (int)kchunk; p.splits = splits;
+    p.tiles_m = (M + 255) / 256; p.tiles_n = (C + 255) / 256;
+    p.quad_ok = 1;
+    p.batch = batch; p.dy_bstride = (long long)M * K; p.x_bstride = (long long)C * K;
+    const long long blocks = (long long)p.tiles_m * p.tiles_n * splits * batch;
+    if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
+    int rc = launch_dma<1, false>(p, blocks, stream);
+    if (rc) return rc;
+    if (splits > 1) {
+        const long long wn = (long long)batch * M * C;
+        if (wn % 4 == 0 && dcfp_aligned16(out)) {
+            const long long n4 = wn / 4;
+            hipLaunchKernelGGL(splitk_reduce_vec4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                               static_cast<const float*>(workspace), out, n4, wn, splits);
+        } else {
+            long long b = (wn + 255) / 256;
+            if (b > 4096) b = 4096;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(256), 0, stream,
+                               static_cast<const float*>(workspace), out, wn, splits);
+        }
+    }
+    DCFP_RETURN_LAUNCH();
+}
+
+static bool wino_wgrad_pass(const DcfpConvDesc* d);
+
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
+    if (wino_wgrad_pass(d)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false>)");
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
                        pl.cfg == 4 ? "4,1,2,2" : "2,2,1,1";
@@ -850,14 +925,47 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     return snprintf(buf, buf_len, "wgrad2_kernel<%d,%s>", d->KH * d->KW, args);
 }
 
-// (the weight-gradient kernels execute every K-step: a tile of dW mixes all nine taps)
-double dcfp_wgrad_exec_fraction(const DcfpConvDesc*) { return 1.0; }
+// conv_winograd.hip
+bool dcfp_wino_wgrad_ok(int N, int H, int W, int d, int M, int C);
+size_t dcfp_wino_wgrad_workspace_bytes(int N, int H, int W, int d, int M, int C);
+double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck);
+int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, const float* x, long long x_nstride,
+                        int x_pitch, float* dw, int N, int M, int C, int H, int W, int d, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream);
+
+// Winograd F(2x2, 3x3) weight gradient where the cost model (same-box measurements, profiles/r02_winograd_ab.txt) says
+// it beats the direct LDS-DMA kernel: direct = nominal FLOPs at 130 TF (123 on dense dilation-1 operands);
+// Winograd = 16/36 x tile padding of them at 125 TF plus the x / dy transform passes at 4.2 / 5 TB/s.
+// DCFP_CONV_WINOGRAD: 0 off, 1 model (default), 2 wherever eligible.
+static bool wino_wgrad_pass(const DcfpConvDesc* d) {
+    static const int mode = [] { const char* e = getenv("DCFP_CONV_WINOGRAD"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return false;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->Hout != d->H || d->Wout != d->W) return false;
+    if (math_bf16x3()) return false;
+    if (!dcfp_wino_wgrad_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)) return false;
+    if (mode == 2) return true;
+    const double pix = (double)d->N * d->H * d->W;
+    const double nominal = 2.0 * pix * d->Cout * (double)d->Cin * 9.0;
+    const bool dense_d1 = wgrad_dma_mixed(d) && !(d->x_pitch && d->x_pitch != d->W);
+    const double t_direct = nominal / (dense_d1 ? 123e12 : 130e12);
+    const double f = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
+    const double tiles = f * 9.0 / 16.0 * pix;
+    const double t_wino = nominal * f / 125e12 + (4.0 * pix * d->Cin + 64.0 * tiles * d->Cin) / 4.2e12 +
+                          (4.0 * pix * d->Cout + 64.0 * tiles * d->Cout) / 5.0e12 + 30e-6;
+    return t_wino < 0.97 * t_direct;
+}
+
+// share of the nominal multiply-adds issued (the direct kernels execute every K-step: a tile of dW mixes all nine taps)
+double dcfp_wgrad_exec_fraction(const DcfpConvDesc* d) {
+    return wino_wgrad_pass(d) ? dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) : 1.0;
+}
 
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
 
 extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
     if (pass == DCFP_CONV_FWD || pass == DCFP_CONV_DGRAD) return dcfp_conv2d_fwd_dgrad_workspace_bytes_(d, pass);
     if (pass != DCFP_CONV_WGRAD || check_desc(d) != DCFP_OK) return 0;
+    if (wino_wgrad_pass(d)) return dcfp_wino_wgrad_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
     const Plan pl = make_plan(d);
     if (pl.splits <= 1) return 0;
     return (size_t)pl.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
@@ -870,6 +978,17 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !x || !dw) return DCFP_E_BADDESC;
+    if (wino_wgrad_pass(d)) {
+        const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout, xp = d->x_pitch ? d->x_pitch : d->W;
+        const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;
+        rc = dcfp_wino_wgrad_run(dy, dyn, dyp, x, (long long)d->Cin * d->H * xp, xp, dw, d->N, d->Cout, d->Cin, d->H, d->W,
+                                 d->dil, workspace, workspace_bytes, dcfp_s(stream));
+        if (rc) return rc;
+        if (db)
+            hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(256), 0, dcfp_s(stream), dy, dyn, db, d->N,
+                               d->Hout * d->Wout);
+        DCFP_RETURN_LAUNCH();
+    }
     const Plan pl = make_plan(d);
     const int T = d->KH * d->KW;
     const long long wn = (long long)d->Cout * d->Cin * T;
@@ -891,6 +1010,7 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     p.Kpix = d->N * p.P;
     p.kchunk = pl.kchunk; p.splits = pl.splits; p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
     p.quad_ok = (d->Wout % 4 == 0) ? 1 : 0;
+    p.batch = 1; p.dy_bstride = p.x_bstride = 0;
     {   // 31-bit byte offsets relative to the first image of a split
         const long long span = (long long)pl.kchunk / p.P + 2;
         const long long big = p.dy_nstride > p.x_nstride ? p.dy_nstride : p.x_nstride;

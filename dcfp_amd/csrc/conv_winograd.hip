@@ -96,12 +96,21 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
 // share an input element find it in L1 / L2), 16 coalesced stores.  (A version that staged the strip's four input
 // rows in LDS with coalesced loads measured 4...19 % slower per conv: one barrier per 128 tiles, half the threads idle.)
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, long long x_nstride, int pitch,
-                                                         int C, int H, int W, int d, int TH, int TW,
-                                                         float* __restrict__ V, long long T) {
+                                                         int N, int C, int H, int W, int d, int TH, int TW,
+                                                         float* __restrict__ V, long long rowlen) {
+    // rows of V are `rowlen` floats: N * TH * TW tiles, then (weight-gradient use) a zero tail up to a multiple of 16
     const int tpi = TH * TW;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= tpi) return;
-    const int n = blockIdx.y, c = blockIdx.z;
+    const long long tg = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tg >= rowlen) return;
+    const int c = blockIdx.z;
+    const int n = (int)(tg / tpi), t = (int)(tg - (long long)n * tpi);
+    const long long plane = (long long)C * rowlen;
+    float* dst = V + (long long)c * rowlen + tg;
+    if (n >= N) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[k * plane] = 0.f;
+        return;
+    }
     const int trow = t / TW, tcol = t - trow * TW;
     const int h0 = trow + d * (trow / d) - d, w0 = tcol + d * (tcol / d) - d;
     const float* src = x + (long long)n * x_nstride + (long long)c * H * pitch;
@@ -125,14 +134,76 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
         q[2][s] = p[2][s] - p[1][s];
         q[3][s] = p[1][s] - p[3][s];
     }
-    const long long plane = (long long)C * T;
-    float* dst = V + (long long)c * T + (long long)n * tpi + t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         dst[(4 * r + 0) * plane] = q[r][0] - q[r][2];
         dst[(4 * r + 1) * plane] = q[r][1] + q[r][2];
         dst[(4 * r + 2) * plane] = q[r][2] - q[r][1];
         dst[(4 * r + 3) * plane] = q[r][1] - q[r][3];
+    }
+}
+
+// Weight gradient, dy side: Y[xi][m][t] = (A dy_t A^T)[xi] of the 2x2 output-gradient tile t (zeros outside the image and
+// in the rows' tail), A = [1 0; 1 1; 1 -1; 0 -1].  grid (ceil(rowlen / 256), 1, M)
+__global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ dy, long long dy_nstride, int pitch, int N,
+                                                      int M, int H, int W, int d, int TH, int TW, float* __restrict__ Y,
+                                                      long long rowlen) {
+    const int tpi = TH * TW;
+    const long long tg = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tg >= rowlen) return;
+    const int m = blockIdx.z;
+    const int n = (int)(tg / tpi), t = (int)(tg - (long long)n * tpi);
+    const long long plane = (long long)M * rowlen;
+    float* dst = Y + (long long)m * rowlen + tg;
+    float g[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (n < N) {
+        const int trow = t / TW, tcol = t - trow * TW;
+        const int ho = trow + d * (trow / d), wo = tcol + d * (tcol / d);
+        const float* src = dy + (long long)n * dy_nstride + (long long)m * H * pitch;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int h = ho + r * d, ww = wo + s * d;
+                if (h < H && ww < W) g[r][s] = src[(long long)h * pitch + ww];
+            }
+    }
+    // A g: rows (4 x 2), then (A g) A^T: columns
+    float u[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u[0][s] = g[0][s];
+        u[1][s] = g[0][s] + g[1][s];
+        u[2][s] = g[0][s] - g[1][s];
+        u[3][s] = -g[1][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dst[(4 * r + 0) * plane] = u[r][0];
+        dst[(4 * r + 1) * plane] = u[r][0] + u[r][1];
+        dst[(4 * r + 2) * plane] = u[r][0] - u[r][1];
+        dst[(4 * r + 3) * plane] = -u[r][1];
+    }
+}
+
+// dw[m][c][3][3] = G^T dU G,  dU[xi][m][c]
+__global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, long long mc, float* __restrict__ dw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mc) return;
+    float t[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float u0 = dU[(0 + s) * mc + i], u1 = dU[(4 + s) * mc + i], u2 = dU[(8 + s) * mc + i], u3 = dU[(12 + s) * mc + i];
+        t[0][s] = u0 + 0.5f * (u1 + u2);
+        t[1][s] = 0.5f * (u1 - u2);
+        t[2][s] = 0.5f * (u1 + u2) + u3;
+    }
+    float* o = dw + i * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[3 * r + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+        o[3 * r + 1] = 0.5f * (t[r][1] - t[r][2]);
+        o[3 * r + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
     }
 }
 
@@ -226,8 +297,8 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     }
     const int tpi = pl.TH * pl.TW;
     if (Ck > 65535 || M > 65535 || N > 65535) return DCFP_E_UNSUPPORTED;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((tpi + 255) / 256), (unsigned)N, (unsigned)Ck), dim3(256), 0,
-                       stream, in, in_nstride, in_pitch > 0 ? in_pitch : W, Ck, H, W, d, pl.TH, pl.TW, V, pl.T);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((pl.T + 255) / 256), 1, (unsigned)Ck), dim3(256), 0, stream, in,
+                       in_nstride, in_pitch > 0 ? in_pitch : W, N, Ck, H, W, d, pl.TH, pl.TW, V, pl.T);
     const int rc = dcfp_igemm2_run(V, (long long)Ck * pl.T, nullptr, 0, 0, nullptr, Mb, (long long)M * pl.T, 16, M, Ck, 1,
                                    N * pl.TH, pl.TW, N * pl.TH, pl.TW, 1, 1, 0, 1, 0, U,
                                    (size_t)pl.u_floats * sizeof(float), stream, nullptr, nullptr, nullptr, 0, nullptr,
@@ -235,5 +306,63 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     if (rc) return rc;
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((tpi + 255) / 256), (unsigned)N, (unsigned)M), dim3(256), 0,
                        stream, Mb, pl.T, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate);
+    DCFP_RETURN_LAUNCH();
+}
+
+// ---------------------------------------------------------------- weight gradient
+//   dU[xi][m][c] = sum_t (A dy_t A^T)[xi] * (B^T x_t B)[xi],   dw = G^T dU G
+// 16 products over the tiles instead of 36 over the pixels: the x transform of the forward pass, a 2x2 -> 4x4 transform
+// of dy, ONE launch of the LDS-DMA 1x1 weight-gradient kernel over 16 independent problems (conv_wgrad.hip), and a
+// 16 -> 9 transform of the result.
+size_t dcfp_wgrad_batched_workspace_bytes(int batch, int M, int C, long long K, int* splits_out);
+int dcfp_wgrad_batched_run(const float* a, const float* bmat, float* out, int batch, int M, int C, long long K,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+namespace {
+struct WinoWgradPlan { WinoPlan pl; long long T16, v, y, du, slabs; };
+WinoWgradPlan wino_wgrad_plan(int N, int H, int W, int d, int M, int C) {
+    WinoWgradPlan w;
+    w.pl = wino_plan(N, H, W, d, M, C);
+    w.T16 = (w.pl.T + 15) / 16 * 16;
+    w.v = align64(16LL * C * w.T16);
+    w.y = align64(16LL * M * w.T16);
+    w.du = align64(16LL * M * C);
+    w.slabs = align64((long long)(dcfp_wgrad_batched_workspace_bytes(16, M, C, w.T16, nullptr) / sizeof(float)));
+    return w;
+}
+}  // namespace
+
+bool dcfp_wino_wgrad_ok(int N, int H, int W, int d, int M, int C) {
+    if (M < 256 || C < 256) return false;
+    const WinoWgradPlan w = wino_wgrad_plan(N, H, W, d, M, C);
+    if (4 * w.pl.T > (long long)N * H * W * 27 / 20) return false;
+    if (w.T16 >= (1LL << 30) || (long long)M * w.T16 >= (1LL << 29) || (long long)C * w.T16 >= (1LL << 29)) return false;
+    return M <= 65535 && C <= 65535;
+}
+
+size_t dcfp_wino_wgrad_workspace_bytes(int N, int H, int W, int d, int M, int C) {
+    const WinoWgradPlan w = wino_wgrad_plan(N, H, W, d, M, C);
+    return (size_t)(w.v + w.y + w.du + w.slabs) * sizeof(float);
+}
+
+int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, const float* x, long long x_nstride,
+                        int x_pitch, float* dw, int N, int M, int C, int H, int W, int d, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream) {
+    const WinoWgradPlan w = wino_wgrad_plan(N, H, W, d, M, C);
+    if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_wgrad_workspace_bytes(N, H, W, d, M, C))
+        return DCFP_E_WORKSPACE;
+    float* V = static_cast<float*>(workspace);
+    float* Y = V + w.v;
+    float* dU = Y + w.y;
+    float* slabs = dU + w.du;
+    const unsigned gx = (unsigned)((w.T16 + 255) / 256);
+    hipLaunchKernelGGL(wino_input_kernel, dim3(gx, 1, (unsigned)C), dim3(256), 0, stream, x, x_nstride,
+                       x_pitch > 0 ? x_pitch : W, N, C, H, W, d, w.pl.TH, w.pl.TW, V, w.T16);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(gx, 1, (unsigned)M), dim3(256), 0, stream, dy, dy_nstride,
+                       dy_pitch > 0 ? dy_pitch : W, N, M, H, W, d, w.pl.TH, w.pl.TW, Y, w.T16);
+    const int rc = dcfp_wgrad_batched_run(Y, V, dU, 16, M, C, w.T16, slabs, (size_t)w.slabs * sizeof(float), stream);
+    if (rc) return rc;
+    const long long mc = (long long)M * C;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, stream, dU, mc, dw);
     DCFP_RETURN_LAUNCH();
 }

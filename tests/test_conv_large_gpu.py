@@ -90,8 +90,10 @@ def test_large_conv_parity(cuda, mode):
     assert len(res) == len(CASES)
     fwd_kernel, wgrad_kernel = ("igemm3_kernel", "wgrad3_kernel") if mode == "bf16x3" else \
         ("igemm2_", "wgrad2_kernel")     # igemm2_kernel<...>, igemm2_dma_kernel<9,..> or the persistent igemm2_dma1p_kernel
-    assert sum(rec["kernels"][2].startswith(wgrad_kernel) for rec in res) >= 2, res
-    if mode == "f32":   # the +-1 tap case goes through the LDS-DMA wgrad with shifted 16-byte copies
+    wino = WINO and mode == "f32"        # (the wide 3x3 cases then take the Winograd weight gradient)
+    assert sum(rec["kernels"][2].startswith(wgrad_kernel) or (wino and rec["kernels"][2].startswith("winograd_f2x2_3x3"))
+               for rec in res) >= 2, res
+    if mode == "f32" and not wino:   # the +-1 tap case goes through the LDS-DMA wgrad with shifted 16-byte copies
         assert res[3]["kernels"][2] == "wgrad_dma_kernel<9,true>", res[3]["kernels"]
     for rec in res:
         N, Cin, H, W, Cout, k, p, d = rec["case"]
@@ -173,7 +175,8 @@ def test_row_pitched_operands_bit_identical(cuda, shape):
     # un-mixed LDS-DMA kernels (the ragged-M one where the channel count is off the 256 grid); same K order everywhere
     assert all(n in ("igemm2_dma_kernel<9,false>", "igemm2_dma8_kernel<9>") or (WINO and n.startswith("winograd_f2x2_3x3"))
                for n in names[:2]), names
-    assert names[2] in ("wgrad_dma_kernel<9,false>", "wgrad_dma_kernel<9,false,true>"), names
+    assert names[2] in ("wgrad_dma_kernel<9,false>", "wgrad_dma_kernel<9,false,true>") or \
+        (WINO and names[2].startswith("winograd_f2x2_3x3")), names
     xp = ops.pitched_buffer(tuple(x.shape), pitch, "test_x", cuda); xp.copy_(x)
     dyp = ops.pitched_buffer(tuple(dy.shape), pitch, "test_dy", cuda); dyp.copy_(dy)
     assert ops._pitch_of(xp) == pitch and float(xp.as_strided((N, Cin, H, pitch - W), xp.stride(), xp.storage_offset() + W).abs().sum()) == 0.0

@@ -21,7 +21,10 @@ for (N, Cin, H, W, Cout, d) in [(2, 256, 64, 128, 256, 2), (2, 256, 50, 68, 512,
     seed = torch.randn(x.shape, generator=g)
     acc = seed.to(dev).clone()
     ops.conv2d_dgrad(dyd, wd, tuple(x.shape), 1, d, d, out=acc, accumulate=True)
+    dw, _ = ops.conv2d_wgrad(dyd, xd, tuple(w.shape), 1, d, d)
+    wname = ops.conv_kernel_name(desc, _lib.CONV_WGRAD)
     torch.cuda.synchronize()
+    refdw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, d, d)
     ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, d, d)
     refdx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
     e = lambda a, b: float((a.cpu().double() - b).abs().max() / b.abs().max())
@@ -29,5 +32,6 @@ for (N, Cin, H, W, Cout, d) in [(2, 256, 64, 128, 256, 2), (2, 256, 50, 68, 512,
     out[f"{N}x{Cin}x{H}x{W}->{Cout} d{d}"] = {"kernel": name, "fwd_max": e(y, ref), "fwd_rel": r(y, ref),
                                                "dgrad_max": e(dx, refdx), "dgrad_rel": r(dx, refdx),
                                                "acc_max": e(acc, refdx + seed.double()),
+                                               "wgrad_kernel": wname, "wgrad_max": e(dw, refdw), "wgrad_rel": r(dw, refdw),
                                                "frac": ops.conv_executed_fraction(desc, _lib.CONV_FWD)}
 print("WINO " + json.dumps(out, indent=1))
