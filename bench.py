@@ -364,26 +364,33 @@ def main():
     # conv kernels (fp32-grade products on the bf16 matrix cores; DESIGN.md "bf16x3").  The library
     # reads the switch once per process, so the leg runs in a child after this process let go of
     # its device memory.
-    alt = None
+    alt = direct = None
     if (rank == 0 and world == 1 and not args.no_alt and not args.force_ddp and not args.channel_cfg
-            and os.environ.get("DCFP_CONV_MATH", "") == ""):
+            and os.environ.get("DCFP_CONV_MATH", "") == "" and os.environ.get("DCFP_CONV_WINOGRAD", "") == ""):
         del model, seg_model, optimizer, train_pruning, images, labels
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        env = dict(os.environ, DCFP_CONV_MATH="bf16x3")
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup",
                str(args.warmup), "--backbone", args.backbone, "--batch", str(args.batch), "--size", args.size,
                "--no-cpu-baseline", "--no-roofline", "--no-alt"]
-        try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-            rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-            alt = {"math": "bf16x3: fp32 operands split into 3 bf16 planes, 6 bf16 MFMA products per fp32 "
-                           "product, fp32 accumulate (opt-in DCFP_CONV_MATH=bf16x3; not the headline)",
-                   "value": rec["value"], "unit": "images/s", "ms_per_step": rec["ms_per_step"],
-                   "final_loss": rec["final_loss"]}
-        except Exception as exc:  # the leg is informational; the headline above stands on its own
-            alt = {"math": "bf16x3", "error": repr(exc)[:200]}
+
+        def leg(env_extra, what):
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+                rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                return {"what": what, "value": rec["value"], "unit": "images/s", "ms_per_step": rec["ms_per_step"],
+                        "final_loss": rec["final_loss"]}
+            except Exception as exc:  # the legs are informational; the headline above stands on its own
+                return {"what": what, "error": repr(exc)[:200]}
+        # the same step on the direct conv kernels only (no Winograd): what the headline would be without the
+        # algebraic restructuring of the wide 3x3 convs; same fp32 multiplicands either way
+        direct = leg({"DCFP_CONV_WINOGRAD": "0"},
+                     "DCFP_CONV_WINOGRAD=0: every conv on the direct implicit-GEMM kernels (round-2 kernels of DESIGN 3a)")
+        alt = leg({"DCFP_CONV_MATH": "bf16x3"},
+                  "bf16x3: fp32 operands split into 3 bf16 planes, 6 bf16 MFMA products per fp32 product, fp32 "
+                  "accumulate (opt-in DCFP_CONV_MATH=bf16x3; not the headline)")
+        alt["math"] = "bf16x3"
 
     if rank == 0:
         out = {"metric": "training images/sec at 1024x2048 DeepLabv3-R101", "value": value, "unit": "images/s",
@@ -395,6 +402,9 @@ def main():
                "config": {"workload": ("PRUNED (" + args.channel_cfg + ") " if args.channel_cfg else "") +
                                       f"DeepLabv3-{args.backbone}+ASPP os8, {args.batch}x3x{H}x{W} per GPU, "
                                       "CE+0.4*deepsup CE (fused upsample), " +
+                                      ("" if os.environ.get("DCFP_CONV_WINOGRAD", "") == "0" else
+                                       "3x3 stride-1 convs with >= 256 channels as fp32 Winograd F(2x2,3x3) "
+                                       "(fwd / dgrad / wgrad), all other convs direct implicit GEMM, ") +
                                       ("SyncBN + gradient all-reduce over RCCL, " if ddp else "") +
                                       "EIC step, SGD m0.9 wd5e-4",
                           "global_batch": global_batch, "parallelism": f"dp{world}"},
@@ -402,7 +412,7 @@ def main():
                "grad_allreduce_launches_per_step": getattr(getattr(model, "reducer", None), "launched", None) if ddp else None,
                "sgd_table_rebuilds": sgd_rebuilds,
                "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone, args.channel_cfg) == (1024, 2048, "resnet101", None) else None,
-               "roofline": roof, "cpu_baseline": cpu, "alt_math": alt, "detail": extra}
+               "roofline": roof, "cpu_baseline": cpu, "direct_conv": direct, "alt_math": alt, "detail": extra}
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if dist.is_initialized():

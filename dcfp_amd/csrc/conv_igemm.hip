@@ -94,7 +94,7 @@ static bool igemm3_ok(int M, long long px, int sn, int sd) {
 // Winograd F(2x2, 3x3) (conv_winograd.hip) takes a wide 3x3 stride-1 pad == dil conv, forward or dgrad, where a
 // cost model calibrated on this chip says it is faster than the direct LDS-DMA kernel (same-box measurements,
 // profiles/r02_winograd_ab.txt): direct = nominal FLOPs x executed share (dead kernel rows) at 143 TF; Winograd =
-// 16/36 of the nominal FLOPs x tile padding at 118 TF (K = 256) ... 135 TF (K >= 512) plus the two transform passes
+// 16/36 of the nominal FLOPs x tile padding at 118 ... 135 TF (by GEMM shape) plus the two transform passes
 // at 4.2 / 5.4 TB/s.  DCFP_CONV_WINOGRAD: 0 off, 1 model (default), 2 wherever eligible (A/B).
 static bool wino_pass(const DcfpConvDesc* d, int pass) {
     static const int mode = [] { const char* e = getenv("DCFP_CONV_WINOGRAD"); return e ? atoi(e) : 1; }();
@@ -114,7 +114,9 @@ static bool wino_pass(const DcfpConvDesc* d, int pass) {
     const double t_direct = nominal * f_direct / 143e12;
     const double f_wino = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, M, Ck);
     const double tiles = f_wino * 9.0 / 16.0 * d->N * (double)d->H * d->W;          // T
-    const double rate = Ck <= 256 ? 118e12 : Ck < 512 ? 126e12 : 135e12;
+    // batched GEMM rate by shape class (measured): K = 256 is store-bound (118 TF at M = 256, 130 at M >= 1024),
+    // deeper K runs at 127 TF with one row of M tiles and 135 TF with several
+    const double rate = Ck <= 256 ? (M >= 1024 ? 130e12 : 118e12) : (M <= 256 ? 127e12 : 135e12);
     const double pix = (double)d->N * d->H * d->W;
     const double t_in = (4.0 * pix * Ck + 64.0 * tiles * Ck) / 4.2e12;
     const double t_out = (64.0 * tiles * M + 4.0 * pix * M * (fwd ? 1.0 : 2.0)) / 5.4e12;
