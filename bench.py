@@ -134,7 +134,11 @@ def roofline_from_profile(recs, images_per_step, step_s):
             a[0] += work; a[1] += ms; a[2] += 1
             bn_bytes += work; bn_ms += ms
     convs = {k: v for k, v in agg.items() if "kernel" in k}
-    dom = max(convs, key=lambda k: convs[k][1])
+    # dominant = the single-kernel conv entry with the most time (its rocprofv3 row must agree with the live
+    # average); the Winograd ops are three or four kernels under one event pair - they are listed in `detail`
+    # with the MFMA work their GEMMs issue, and profiles/ holds their components' rows
+    single = {k: v for k, v in convs.items() if not k.startswith("winograd")} or convs
+    dom = max(single, key=lambda k: single[k][1])
     w, ms, cnt, w_exec = convs[dom]
     # HBM-side bytes per launch from the committed PMC profile (cannot be collected inside this
     # process): corrected FETCH_SIZE + WRITE_SIZE of the same kernel instance on its dominant shape

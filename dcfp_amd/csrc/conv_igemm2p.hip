@@ -46,9 +46,11 @@ constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, 
 
 // WPI: every image has its own weight copy (p.wp_nstride floats apart) - the batched GEMM of conv_winograd.hip,
 // a kernel instance of its own so that profiles tell it from the 1x1 convs
-template <bool ACC, bool WPI = false>
-__global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles, int dbg) {
-    constexpr int TM = 4, TN = 4, WN = 2, BM = 256, BN = 256;
+// TM_ = 2: 128 x 256 tiles, 128 accumulator registers per lane - TWO workgroups per CU, so that one's epilogue
+// stores and barrier waits overlap the other's MFMAs (the K = 256 layers, whose 256 x 256 tiles are store-bound).
+template <bool ACC, bool WPI = false, int TM_ = 4>
+__global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles, int dbg) {
+    constexpr int TM = TM_, TN = 4, WN = 2, BM = 64 * TM_, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BK][BM]
     float* Bs = smem + 2 * BK * BM;    // [2][BK][BN]
@@ -65,6 +67,7 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
     // file: nothing loop-carried may spill), the lane part is lane * 16 for A and the pixel quad for B
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);
     const unsigned lane16 = lane * 16u;
+    const unsigned a2_voff = (unsigned)((lane >> 5) * p.Mpad) * 4u + (unsigned)(lane & 31) * 16u;   // TM == 2: two k-rows per copy
     const u32x4 a_desc = make_desc(p.wp, 0x7ffffffcu);
     const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr)As, lds_b0 = (unsigned)(size_t)(lds_ptr)Bs;
 
@@ -104,12 +107,22 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
         constexpr int piece = decltype(piece_)::value;
         constexpr int q = piece >> 1;
         if constexpr ((piece & 1) == 0) {
-            const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)((ld_cb * BK + 4 * wid_s + q) * p.Mpad) * 4u);
-            const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid_s + q) * BM) * 4u);
-            const unsigned av = lane16;
-            const u32x4 ad = a_desc;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+            if constexpr (TM == 4) {
+                const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)((ld_cb * BK + 4 * wid_s + q) * p.Mpad) * 4u);
+                const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid_s + q) * BM) * 4u);
+                const unsigned av = lane16;
+                const u32x4 ad = a_desc;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+            } else if constexpr (q < 2) {
+                // a 128-float k-row is 512 bytes: one instruction copies rows 4w + 2q (lanes 0..31) and 4w + 2q + 1
+                const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)((ld_cb * BK + 4 * wid_s + 2 * q) * p.Mpad) * 4u);
+                const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid_s + 2 * q) * BM) * 4u);
+                const unsigned av = a2_voff;
+                const u32x4 ad = a_desc;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+            }
         } else {
             // channel-row offset in the VGPR offset: the descriptor's bound must see it (rows past Ck -> zeros)
             const unsigned b_cb = (unsigned)__builtin_amdgcn_readfirstlane((ld_cb * BK + 4 * wid_s + q) * HiWi) * 4u;
@@ -223,7 +236,7 @@ __global__ void __launch_bounds__(256) igemm2_dma1p_kernel(const Igemm2Params p,
                 }
             }
         } else {
-            if constexpr (!ACC) {
+            if constexpr (!ACC && TM == 4) {
                 if (p.stat_part) {
                     // BatchNorm statistics of this tile's rows: see igemm2_dma_kernel (same arithmetic, same order)
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -313,10 +326,16 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
         else
             cus = 256;
     }
+    // 128-row tiles, two workgroups per CU: DCFP_IGEMM_P128 = 0 off, 1 the K <= 256 problems (default), 2 all
+    static const int p128 = [] { const char* e = getenv("DCFP_IGEMM_P128"); return e ? atoi(e) : 1; }();
+    const bool half = !p.stat_part && p.Mpad % 256 == 0 && (p128 == 2 || (p128 == 1 && p.CkP <= 256));
+    Igemm2Params q = p;
+    if (half) q.tiles_m = p.tiles_m * 2;
     const long long groups = ((long long)p.tiles_n_total + 7) / 8;
-    const long long total = groups * 8 * p.tiles_m;
+    const long long total = groups * 8 * q.tiles_m;
     if (total > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
-    long long blocks = total < cus ? total : cus;
+    const long long slots = half ? 2LL * cus : cus;
+    long long blocks = total < slots ? total : slots;
     int dbg = 0;
 #ifdef DCFP_P_DEBUG
     if (const char* e = getenv("DCFP_DBG_P_BLOCKS")) blocks = atoll(e) < blocks ? atoll(e) : blocks;
@@ -324,17 +343,18 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
 #endif
     blocks = blocks / 8 * 8;                       // grid % 8 == 0 keeps a workgroup's tiles on one pixel-tile residue
     if (blocks < 8) blocks = total < 8 ? total : 8;
-    const size_t lds = (size_t)(2 * BK * 512 + (p.stat_part ? kStatFloats : 0)) * sizeof(float);
+    const size_t lds = (size_t)(2 * BK * (half ? 384 : 512) + (p.stat_part ? kStatFloats : 0)) * sizeof(float);
     auto launch = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, (int)total, dbg);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, q, (int)total, dbg);
         DCFP_RETURN_LAUNCH();
     };
     if (p.wp_nstride) {
         if (p.accumulate) return DCFP_E_UNSUPPORTED;
-        return launch(igemm2_dma1p_kernel<false, true>);
+        return half ? launch(igemm2_dma1p_kernel<false, true, 2>) : launch(igemm2_dma1p_kernel<false, true>);
     }
+    if (half) return p.accumulate ? launch(igemm2_dma1p_kernel<true, false, 2>) : launch(igemm2_dma1p_kernel<false, false, 2>);
     return p.accumulate ? launch(igemm2_dma1p_kernel<true>) : launch(igemm2_dma1p_kernel<false>);
 }

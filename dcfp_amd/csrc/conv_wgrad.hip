@@ -434,7 +434,9 @@ int num_cus() {
 // all 8 row blocks of dy, 8 x 2 MFMA tiles; row blocks at or past M = Cout are dead for the whole tile and their
 // MFMAs are skipped - the cost follows ceil(Cout / 32) instead of ceil(Cout / 256) * 8 (or a register-staged
 // 128- / 64-row tile).  Same staging, same K order per output element as the 2 x 2 layout.
-template <int TAPS, bool MIXED, bool WIDE = false>
+// BATCH: p.batch independent problems in one launch (the Winograd weight gradient's 16 components) - an instance of
+// its own so that profiles tell it from the 1x1 convs' weight gradients
+template <int TAPS, bool MIXED, bool WIDE = false, bool BATCH = false>
 __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     constexpr int TM = WIDE ? 8 : 4, TN = WIDE ? 2 : 4, WN = WIDE ? 4 : 2, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -446,7 +448,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         const int full = (p.splits / 8) * 8;
         const int gsz = 8 * tiles;
         int b = blockIdx.x;
-        if (p.batch > 1) {             // problem-major: the workgroups of one problem share its operands in L2
+        if constexpr (BATCH) {         // problem-major: the workgroups of one problem share its operands in L2
             const int per = tiles * p.splits;
             bi = b / per;
             b -= bi * per;
@@ -811,10 +813,10 @@ static bool wgrad_dma_ok(const DcfpConvDesc* d, int cfg) {
 }
 static bool wgrad_dma_mixed(const DcfpConvDesc* d) { return d->KH == 3 && ((d->pad | d->dil) & 3) != 0; }
 
-template <int TAPS, bool MIXED, bool WIDE = false>
+template <int TAPS, bool MIXED, bool WIDE = false, bool BATCH = false>
 int launch_dma(const WgradParams& p, long long blocks, hipStream_t stream) {
     const size_t lds = (size_t)2 * 512 * BK * sizeof(float);
-    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED, WIDE>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED, WIDE, BATCH>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DCFP_OK : (int)e;
 }
@@ -892,7 +894,7 @@ int dcfp_wgrad_batched_run(const float* a, const float* bmat, float* out, int ba
     p.batch = batch; p.dy_bstride = (long long)M * K; p.x_bstride = (long long)C * K;
     const long long blocks = (long long)p.tiles_m * p.tiles_n * splits * batch;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
-    int rc = launch_dma<1, false>(p, blocks, stream);
+    int rc = launch_dma<1, false, false, true>(p, blocks, stream);
     if (rc) return rc;
     if (splits > 1) {
         const long long wn = (long long)batch * M * C;
@@ -913,7 +915,7 @@ int dcfp_wgrad_batched_run(const float* a, const float* bmat, float* out, int ba
 static bool wino_wgrad_pass(const DcfpConvDesc* d);
 
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
-    if (wino_wgrad_pass(d)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false>)");
+    if (wino_wgrad_pass(d)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false,false,true>)");
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
                        pl.cfg == 4 ? "4,1,2,2" : "2,2,1,1";

@@ -91,30 +91,66 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
     }
 }
 
-// V[xi][c][n * TH * TW + t] = (B^T d B)[xi] of tile t of image n, channel c.  grid (ceil(TH*TW / 256), N, C).
-// One tile per thread, 16 scalar loads (consecutive tiles read consecutive pixels in runs of d; the four tiles that
-// share an input element find it in L1 / L2), 16 coalesced stores.  (A version that staged the strip's four input
-// rows in LDS with coalesced loads measured 4...19 % slower per conv: one barrier per 128 tiles, half the threads idle.)
+// ---- transform kernels.  A thread handles VEC tiles that are neighbours in a tile row (tcol0 .. tcol0 + VEC - 1,
+// VEC | d or d == 1 with VEC == 1): their pixels are VEC consecutive floats in every row they touch, so loads and
+// stores are 4 / 8 / 16-byte vectors (VEC = 4 for the dilations 4 ... 36, 2 for dilation 2, 1 for dilation 1 and for
+// shapes whose rows are not VEC-aligned).  Rows of the transformed tensors are `rowlen` floats: N * TH * TW tiles,
+// then (weight-gradient use) a zero tail up to a multiple of 16.
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> { typedef float type; };
+template <>
+struct VecT<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <>
+struct VecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 1) v[0] = *p;
+    else {
+        const typename VecT<VEC>::type t = *reinterpret_cast<const typename VecT<VEC>::type*>(p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = t[i];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 1) *p = v[0];
+    else {
+        typename VecT<VEC>::type t;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) t[i] = v[i];
+        *reinterpret_cast<typename VecT<VEC>::type*>(p) = t;
+    }
+}
+
+// V[xi][c][n * TH * TW + t] = (B^T d B)[xi] of tile t of image n, channel c.  grid (ceil(rowlen / VEC / 256), 1, C).
+// (A version that staged the strip's four input rows in LDS with coalesced loads measured 4...19 % slower per conv.)
+template <int VEC>
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, long long x_nstride, int pitch,
                                                          int N, int C, int H, int W, int d, int TH, int TW,
                                                          float* __restrict__ V, long long rowlen) {
-    // rows of V are `rowlen` floats: N * TH * TW tiles, then (weight-gradient use) a zero tail up to a multiple of 16
     const int tpi = TH * TW;
-    const long long tg = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tg = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (tg >= rowlen) return;
     const int c = blockIdx.z;
     const int n = (int)(tg / tpi), t = (int)(tg - (long long)n * tpi);
     const long long plane = (long long)C * rowlen;
     float* dst = V + (long long)c * rowlen + tg;
+    float q[4][4][VEC];
     if (n >= N) {
+        float z[VEC];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dst[k * plane] = 0.f;
+        for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) vstore<VEC>(dst + k * plane, z);
         return;
     }
     const int trow = t / TW, tcol = t - trow * TW;
     const int h0 = trow + d * (trow / d) - d, w0 = tcol + d * (tcol / d) - d;
     const float* src = x + (long long)n * x_nstride + (long long)c * H * pitch;
-    float p[4][4];
+    float p[4][4][VEC];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int h = h0 + r * d;
@@ -122,40 +158,58 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int ww = w0 + s * d;
-            p[r][s] = (hok && (unsigned)ww < (unsigned)W) ? src[(long long)h * pitch + ww] : 0.f;
+            if (hok && ww >= 0 && ww + VEC <= W) vload<VEC>(src + (long long)h * pitch + ww, p[r][s]);
+            else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    p[r][s][v] = (hok && (unsigned)(ww + v) < (unsigned)W) ? src[(long long)h * pitch + ww + v] : 0.f;
+            }
         }
     }
-    // B^T p: rows
-    float q[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        q[0][s] = p[0][s] - p[2][s];
-        q[1][s] = p[1][s] + p[2][s];
-        q[2][s] = p[2][s] - p[1][s];
-        q[3][s] = p[1][s] - p[3][s];
-    }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {        // B^T p: rows
+            q[0][s][v] = p[0][s][v] - p[2][s][v];
+            q[1][s][v] = p[1][s][v] + p[2][s][v];
+            q[2][s][v] = p[2][s][v] - p[1][s][v];
+            q[3][s][v] = p[1][s][v] - p[3][s][v];
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        dst[(4 * r + 0) * plane] = q[r][0] - q[r][2];
-        dst[(4 * r + 1) * plane] = q[r][1] + q[r][2];
-        dst[(4 * r + 2) * plane] = q[r][2] - q[r][1];
-        dst[(4 * r + 3) * plane] = q[r][1] - q[r][3];
+        float o[4][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            o[0][v] = q[r][0][v] - q[r][2][v];
+            o[1][v] = q[r][1][v] + q[r][2][v];
+            o[2][v] = q[r][2][v] - q[r][1][v];
+            o[3][v] = q[r][1][v] - q[r][3][v];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vstore<VEC>(dst + (4 * r + s) * plane, o[s]);
     }
 }
 
 // Weight gradient, dy side: Y[xi][m][t] = (A dy_t A^T)[xi] of the 2x2 output-gradient tile t (zeros outside the image and
-// in the rows' tail), A = [1 0; 1 1; 1 -1; 0 -1].  grid (ceil(rowlen / 256), 1, M)
+// in the rows' tail), A = [1 0; 1 1; 1 -1; 0 -1].  grid (ceil(rowlen / VEC / 256), 1, M)
+template <int VEC>
 __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ dy, long long dy_nstride, int pitch, int N,
                                                       int M, int H, int W, int d, int TH, int TW, float* __restrict__ Y,
                                                       long long rowlen) {
     const int tpi = TH * TW;
-    const long long tg = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tg = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (tg >= rowlen) return;
     const int m = blockIdx.z;
     const int n = (int)(tg / tpi), t = (int)(tg - (long long)n * tpi);
     const long long plane = (long long)M * rowlen;
     float* dst = Y + (long long)m * rowlen + tg;
-    float g[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float g[2][2][VEC];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) g[r][s][v] = 0.f;
     if (n < N) {
         const int trow = t / TW, tcol = t - trow * TW;
         const int ho = trow + d * (trow / d), wo = tcol + d * (tcol / d);
@@ -165,24 +219,83 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int h = ho + r * d, ww = wo + s * d;
-                if (h < H && ww < W) g[r][s] = src[(long long)h * pitch + ww];
-            }
-    }
-    // A g: rows (4 x 2), then (A g) A^T: columns
-    float u[4][2];
+                if (h < H && ww + VEC <= W) vload<VEC>(src + (long long)h * pitch + ww, g[r][s]);
+                else {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u[0][s] = g[0][s];
-        u[1][s] = g[0][s] + g[1][s];
-        u[2][s] = g[0][s] - g[1][s];
-        u[3][s] = -g[1][s];
+                    for (int v = 0; v < VEC; ++v)
+                        if (h < H && ww + v < W) g[r][s][v] = src[(long long)h * pitch + ww + v];
+                }
+            }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        dst[(4 * r + 0) * plane] = u[r][0];
-        dst[(4 * r + 1) * plane] = u[r][0] + u[r][1];
-        dst[(4 * r + 2) * plane] = u[r][0] - u[r][1];
-        dst[(4 * r + 3) * plane] = -u[r][1];
+        float o[4][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            // row r of A g (4 x 2), then its four columns of (A g) A^T
+            const float u0 = r == 0 ? g[0][0][v] : r == 1 ? g[0][0][v] + g[1][0][v] : r == 2 ? g[0][0][v] - g[1][0][v] : -g[1][0][v];
+            const float u1 = r == 0 ? g[0][1][v] : r == 1 ? g[0][1][v] + g[1][1][v] : r == 2 ? g[0][1][v] - g[1][1][v] : -g[1][1][v];
+            o[0][v] = u0; o[1][v] = u0 + u1; o[2][v] = u0 - u1; o[3][v] = -u1;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vstore<VEC>(dst + (4 * r + s) * plane, o[s]);
+    }
+}
+
+// y[n][k][2x2 outputs of tile t] (+)= A^T m A,  m[xi] = Mb[xi][k][n * TH * TW + t].  grid (ceil(TH*TW / VEC / 256), N, K)
+template <int VEC>
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mb, long long T, int K,
+                                                          float* __restrict__ y, long long y_nstride, int H, int W,
+                                                          int d, int TH, int TW, int accumulate) {
+    const int tpi = TH * TW;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (t >= tpi) return;
+    const int n = blockIdx.y, k = blockIdx.z;
+    const int trow = t / TW, tcol = t - trow * TW;
+    const int ho = trow + d * (trow / d), wo = tcol + d * (tcol / d);
+    if (ho >= H || wo >= W) return;
+    const long long plane = (long long)K * T;
+    const float* src = Mb + (long long)k * T + (long long)n * tpi + t;
+    float m[4][4][VEC];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vload<VEC>(src + (4 * r + s) * plane, m[r][s]);
+    float* dst = y + (long long)n * y_nstride + (long long)k * H * W;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int h = ho + r * d;
+        if (h >= H) continue;
+        // A^T m: rows   A^T = [1 1 1 0; 0 1 -1 -1], then columns
+        float u[4][VEC], o[2][VEC];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                u[s][v] = r == 0 ? (m[0][s][v] + m[1][s][v]) + m[2][s][v] : (m[1][s][v] - m[2][s][v]) - m[3][s][v];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            o[0][v] = (u[0][v] + u[1][v]) + u[2][v];
+            o[1][v] = (u[1][v] - u[2][v]) - u[3][v];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ww = wo + s * d;
+            float* e = dst + (long long)h * W + ww;
+            if (ww + VEC <= W) {
+                if (accumulate) {
+                    float old[VEC];
+                    vload<VEC>(e, old);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[s][v] += old[v];
+                }
+                vstore<VEC>(e, o[s]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (ww + v < W) e[v] = accumulate ? e[v] + o[s][v] : o[s][v];
+            }
+        }
     }
 }
 
@@ -255,6 +368,16 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 
 }  // namespace
 
+// tiles per thread of the transform kernels: the widest vector the dilation, the row length and the tensor's alignment allow
+static int wino_vec(int d, int W, int pitch, const float* base, long long nstride, int TW) {
+    static const int cap = [] { const char* e = getenv("DCFP_WINO_VEC"); return e ? atoi(e) : 4; }();   // 1 / 2 / 4 (A/B)
+    for (int v = 4; v > 1; v >>= 1)
+        if (v <= cap && d % v == 0 && W % v == 0 && pitch % v == 0 && nstride % v == 0 && TW % v == 0 &&
+            (reinterpret_cast<uintptr_t>(base) & (4 * v - 1)) == 0)
+            return v;
+    return 1;
+}
+
 // 3x3, stride 1, pad == dil, same-size output; M = output channels of the pass, Ck = reduced channels
 bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck) {
     if (!dcfp_igemm2_persist()) return false;
@@ -297,15 +420,23 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     }
     const int tpi = pl.TH * pl.TW;
     if (Ck > 65535 || M > 65535 || N > 65535) return DCFP_E_UNSUPPORTED;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((pl.T + 255) / 256), 1, (unsigned)Ck), dim3(256), 0, stream, in,
-                       in_nstride, in_pitch > 0 ? in_pitch : W, N, Ck, H, W, d, pl.TH, pl.TW, V, pl.T);
+    const int vec = wino_vec(d, W, in_pitch > 0 ? in_pitch : W, in, in_nstride, pl.TW);
+    const unsigned gin = (unsigned)((pl.T / vec + 255) / 256);
+#define DCFP_WINO_IN(VEC_) hipLaunchKernelGGL(wino_input_kernel<VEC_>, dim3(gin, 1, (unsigned)Ck), dim3(256), 0, stream, in, \
+                                              in_nstride, in_pitch > 0 ? in_pitch : W, N, Ck, H, W, d, pl.TH, pl.TW, V, pl.T)
+    if (vec == 4) DCFP_WINO_IN(4); else if (vec == 2) DCFP_WINO_IN(2); else DCFP_WINO_IN(1);
+#undef DCFP_WINO_IN
     const int rc = dcfp_igemm2_run(V, (long long)Ck * pl.T, nullptr, 0, 0, nullptr, Mb, (long long)M * pl.T, 16, M, Ck, 1,
                                    N * pl.TH, pl.TW, N * pl.TH, pl.TW, 1, 1, 0, 1, 0, U,
                                    (size_t)pl.u_floats * sizeof(float), stream, nullptr, nullptr, nullptr, 0, nullptr,
                                    /*wp_valid=*/1, 0, (long long)pl.CkP * pl.Mpad);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((tpi + 255) / 256), (unsigned)N, (unsigned)M), dim3(256), 0,
-                       stream, Mb, pl.T, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate);
+    const int ovec = wino_vec(d, W, W, out, out_nstride, pl.TW);
+    const unsigned gout = (unsigned)((tpi / ovec + 255) / 256);
+#define DCFP_WINO_OUT(VEC_) hipLaunchKernelGGL(wino_output_kernel<VEC_>, dim3(gout, (unsigned)N, (unsigned)M), dim3(256), 0, \
+                                               stream, Mb, pl.T, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate)
+    if (ovec == 4) DCFP_WINO_OUT(4); else if (ovec == 2) DCFP_WINO_OUT(2); else DCFP_WINO_OUT(1);
+#undef DCFP_WINO_OUT
     DCFP_RETURN_LAUNCH();
 }
 
@@ -355,11 +486,18 @@ int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, con
     float* Y = V + w.v;
     float* dU = Y + w.y;
     float* slabs = dU + w.du;
-    const unsigned gx = (unsigned)((w.T16 + 255) / 256);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(gx, 1, (unsigned)C), dim3(256), 0, stream, x, x_nstride,
-                       x_pitch > 0 ? x_pitch : W, N, C, H, W, d, w.pl.TH, w.pl.TW, V, w.T16);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(gx, 1, (unsigned)M), dim3(256), 0, stream, dy, dy_nstride,
-                       dy_pitch > 0 ? dy_pitch : W, N, M, H, W, d, w.pl.TH, w.pl.TW, Y, w.T16);
+    const int xv = wino_vec(d, W, x_pitch > 0 ? x_pitch : W, x, x_nstride, w.pl.TW);
+    const int yv = wino_vec(d, W, dy_pitch > 0 ? dy_pitch : W, dy, dy_nstride, w.pl.TW);
+#define DCFP_WINO_IN(VEC_) hipLaunchKernelGGL(wino_input_kernel<VEC_>, dim3((unsigned)((w.T16 / VEC_ + 255) / 256), 1, (unsigned)C), \
+                                              dim3(256), 0, stream, x, x_nstride, x_pitch > 0 ? x_pitch : W, N, C, H, W, d, \
+                                              w.pl.TH, w.pl.TW, V, w.T16)
+    if (xv == 4) DCFP_WINO_IN(4); else if (xv == 2) DCFP_WINO_IN(2); else DCFP_WINO_IN(1);
+#undef DCFP_WINO_IN
+#define DCFP_WINO_DY(VEC_) hipLaunchKernelGGL(wino_dy_kernel<VEC_>, dim3((unsigned)((w.T16 / VEC_ + 255) / 256), 1, (unsigned)M), \
+                                              dim3(256), 0, stream, dy, dy_nstride, dy_pitch > 0 ? dy_pitch : W, N, M, H, W, d, \
+                                              w.pl.TH, w.pl.TW, Y, w.T16)
+    if (yv == 4) DCFP_WINO_DY(4); else if (yv == 2) DCFP_WINO_DY(2); else DCFP_WINO_DY(1);
+#undef DCFP_WINO_DY
     const int rc = dcfp_wgrad_batched_run(Y, V, dU, 16, M, C, w.T16, slabs, (size_t)w.slabs * sizeof(float), stream);
     if (rc) return rc;
     const long long mc = (long long)M * C;
