@@ -62,7 +62,9 @@ size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck);
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                  void* workspace, size_t workspace_bytes, hipStream_t stream);
+                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out = nullptr);
+size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
+bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d);      // conv_wgrad.hip
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 bool dcfp_igemm2_persist();
@@ -197,6 +199,30 @@ extern "C" double dcfp_conv2d_executed_fraction(const DcfpConvDesc* d, int pass)
                                            -d->pad, d->dil, pitched)
                : dcfp_igemm2_exec_fraction(d->KH * d->KW, d->Cin, d->Cout, d->N, d->Hout, d->Wout, d->H, d->W, 1, d->stride,
                                            d->pad, -d->dil, pitched);
+}
+
+// Bytes of the transformed input (Winograd V, conv_winograd.hip) that the forward pass of this conv can write into a
+// caller-owned buffer (dcfp_conv2d_fwd_keep_f32_nchw) for its weight gradient to take over
+// (dcfp_conv2d_wgrad_kept_f32_nchw) instead of transforming x again; 0 where either pass is not Winograd.
+extern "C" size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d) {
+    if (check_desc(d) != DCFP_OK) return 0;
+    if (!wino_pass(d, DCFP_CONV_FWD) || !dcfp_wgrad_is_winograd(d)) return 0;
+    return dcfp_wino_xform_bytes(d->N, d->H, d->W, d->dil, d->Cin);
+}
+
+extern "C" int dcfp_conv2d_fwd_keep_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y,
+                                             int64_t y_nstride, float* xform_out, size_t xform_bytes, void* workspace,
+                                             size_t workspace_bytes, dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y || !xform_out) return DCFP_E_BADDESC;
+    const size_t need = dcfp_conv2d_xform_bytes(d);
+    if (need == 0) return DCFP_E_UNSUPPORTED;
+    if (xform_bytes < need) return DCFP_E_WORKSPACE;
+    const int T = 9;
+    return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T, 0, y,
+                         y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, d->H, d->W,
+                         d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), xform_out);
 }
 
 extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,

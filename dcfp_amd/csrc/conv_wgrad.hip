@@ -933,7 +933,8 @@ size_t dcfp_wino_wgrad_workspace_bytes(int N, int H, int W, int d, int M, int C)
 double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck);
 int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, const float* x, long long x_nstride,
                         int x_pitch, float* dw, int N, int M, int C, int H, int W, int d, void* workspace,
-                        size_t workspace_bytes, hipStream_t stream);
+                        size_t workspace_bytes, hipStream_t stream, const float* xform_in = nullptr);
+extern "C" size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d);
 
 // Winograd F(2x2, 3x3) weight gradient where the cost model (same-box measurements, profiles/r02_winograd_ab.txt) says
 // it beats the direct LDS-DMA kernel: direct = nominal FLOPs at 130 TF (123 on dense dilation-1 operands);
@@ -956,6 +957,8 @@ static bool wino_wgrad_pass(const DcfpConvDesc* d) {
                           (4.0 * pix * d->Cout + 64.0 * tiles * d->Cout) / 5.0e12 + 30e-6;
     return t_wino < 0.97 * t_direct;
 }
+
+bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d) { return wino_wgrad_pass(d); }
 
 // share of the nominal multiply-adds issued (the direct kernels execute every K-step: a tile of dW mixes all nine taps)
 double dcfp_wgrad_exec_fraction(const DcfpConvDesc* d) {
@@ -1053,4 +1056,21 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
                            dy, p.dy_nstride, db, d->N, p.P);
     }
     DCFP_RETURN_LAUNCH();
+}
+
+// Weight gradient of a conv whose forward call left its transformed input behind (dcfp_conv2d_fwd_keep_f32_nchw):
+// `xform` replaces x - the x transform pass (a fifth to a quarter of a Winograd weight gradient) is not run again.
+extern "C" int dcfp_conv2d_wgrad_kept_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
+                                               const float* xform, size_t xform_bytes, float* dw, void* workspace,
+                                               size_t workspace_bytes, dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !xform || !dw) return DCFP_E_BADDESC;
+    const size_t need = dcfp_conv2d_xform_bytes(d);
+    if (need == 0) return DCFP_E_UNSUPPORTED;
+    if (xform_bytes < need || !dcfp_aligned16(xform)) return DCFP_E_WORKSPACE;
+    const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout;
+    const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;
+    return dcfp_wino_wgrad_run(dy, dyn, dyp, nullptr, 0, 0, dw, d->N, d->Cout, d->Cin, d->H, d->W, d->dil, workspace,
+                               workspace_bytes, dcfp_s(stream), xform);
 }

@@ -36,7 +36,9 @@ inline long long align64(long long v) { return (v + 63) / 64 * 64; }   // floats
 
 struct WinoPlan {
     int TH, TW;           // tiles per image (rows, columns)
-    long long T;          // tiles over the batch = GEMM pixels per transformed component
+    long long T;          // tiles over the batch
+    long long T16;        // ... rounded up to 16: row length of the transformed tensors = GEMM pixels per component (the
+                          // tail is zeros), the same in the forward pass and the weight gradient, which can take over its V
     int CkP, Mpad;
     long long u_floats, v_floats, m_floats;
 };
@@ -47,11 +49,12 @@ WinoPlan wino_plan(int N, int H, int W, int d, int M, int Ck) {
     pl.TW = d * ((W + 2 * d - 1) / (2 * d));
     pl.TW = (pl.TW + 3) / 4 * 4;                  // GEMM rows of 16-byte quads (the extra tiles have no outputs)
     pl.T = (long long)N * pl.TH * pl.TW;
+    pl.T16 = (pl.T + 15) / 16 * 16;
     pl.CkP = (Ck + dcfp_igemm2_ck_pad() - 1) / dcfp_igemm2_ck_pad() * dcfp_igemm2_ck_pad();
     pl.Mpad = (M + 255) / 256 * 256;
     pl.u_floats = align64(16LL * pl.CkP * pl.Mpad);
-    pl.v_floats = align64(16LL * Ck * pl.T);
-    pl.m_floats = align64(16LL * M * pl.T);
+    pl.v_floats = align64(16LL * Ck * pl.T16);
+    pl.m_floats = align64(16LL * M * pl.T16);
     return pl;
 }
 
@@ -384,11 +387,11 @@ bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck) {
     if (M < 256 || Ck < 256) return false;                       // the transforms cost ~ 1/M + 1/Ck of the GEMM
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (4 * pl.T > (long long)N * H * W * 27 / 20) return false;  // > 35 % padding of the 2d x 2d super-blocks
-    if (pl.T >= (1LL << 26) || 16LL * pl.T >= (1LL << 30)) return false;
-    if ((long long)Ck * pl.T >= (1LL << 29) || (long long)M * pl.T >= (1LL << 29)) return false;
-    const int P = (int)pl.T;
-    if (dcfp_igemm2_use_dma8(1, M, P, 16LL * P, 1, 1, 0, 1, P, pl.TW, false)) return false;
-    return dcfp_igemm2_dma_shape(1, M, Ck, P, 16LL * P, 1, 1, 0, P, pl.TW);
+    if (pl.T16 >= (1LL << 26) || 16LL * pl.T16 >= (1LL << 30)) return false;
+    if ((long long)Ck * pl.T16 >= (1LL << 29) || (long long)M * pl.T16 >= (1LL << 29)) return false;
+    const int P = (int)pl.T16;
+    if (dcfp_igemm2_use_dma8(1, M, P, 16LL * P, 1, 1, 0, 1, P, P, false)) return false;
+    return dcfp_igemm2_dma_shape(1, M, Ck, P, 16LL * P, 1, 1, 0, P, P);
 }
 
 size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck) {
@@ -403,15 +406,18 @@ double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck) {
 }
 
 // in: x (forward) or dy (dgrad), rows at `in_pitch` floats; w with strides (sAm, sAc) as dcfp_igemm2_run takes them
+// xform_out (nullable): 16 * Ck * T16 floats of the caller's that receive the transformed input V instead of the scratch
+// (the weight gradient of the same conv can take it over: dcfp_wino_wgrad_run's xform_in)
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                  void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out) {
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
         return DCFP_E_WORKSPACE;
     float* U = static_cast<float*>(workspace);
-    float* V = U + pl.u_floats;
-    float* Mb = V + pl.v_floats;
+    float* V = xform_out ? xform_out : U + pl.u_floats;
+    float* Mb = U + pl.u_floats + pl.v_floats;
+    if (xform_out && !dcfp_aligned16(xform_out)) return DCFP_E_BADDESC;
     {
         long long b = ((long long)pl.CkP * pl.Mpad + 255) / 256;
         if (b > 4096) b = 4096;
@@ -421,20 +427,20 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     const int tpi = pl.TH * pl.TW;
     if (Ck > 65535 || M > 65535 || N > 65535) return DCFP_E_UNSUPPORTED;
     const int vec = wino_vec(d, W, in_pitch > 0 ? in_pitch : W, in, in_nstride, pl.TW);
-    const unsigned gin = (unsigned)((pl.T / vec + 255) / 256);
+    const unsigned gin = (unsigned)((pl.T16 / vec + 255) / 256);
 #define DCFP_WINO_IN(VEC_) hipLaunchKernelGGL(wino_input_kernel<VEC_>, dim3(gin, 1, (unsigned)Ck), dim3(256), 0, stream, in, \
-                                              in_nstride, in_pitch > 0 ? in_pitch : W, N, Ck, H, W, d, pl.TH, pl.TW, V, pl.T)
+                                              in_nstride, in_pitch > 0 ? in_pitch : W, N, Ck, H, W, d, pl.TH, pl.TW, V, pl.T16)
     if (vec == 4) DCFP_WINO_IN(4); else if (vec == 2) DCFP_WINO_IN(2); else DCFP_WINO_IN(1);
 #undef DCFP_WINO_IN
-    const int rc = dcfp_igemm2_run(V, (long long)Ck * pl.T, nullptr, 0, 0, nullptr, Mb, (long long)M * pl.T, 16, M, Ck, 1,
-                                   N * pl.TH, pl.TW, N * pl.TH, pl.TW, 1, 1, 0, 1, 0, U,
+    const int rc = dcfp_igemm2_run(V, (long long)Ck * pl.T16, nullptr, 0, 0, nullptr, Mb, (long long)M * pl.T16, 16, M, Ck, 1,
+                                   1, (int)pl.T16, 1, (int)pl.T16, 1, 1, 0, 1, 0, U,
                                    (size_t)pl.u_floats * sizeof(float), stream, nullptr, nullptr, nullptr, 0, nullptr,
                                    /*wp_valid=*/1, 0, (long long)pl.CkP * pl.Mpad);
     if (rc) return rc;
     const int ovec = wino_vec(d, W, W, out, out_nstride, pl.TW);
     const unsigned gout = (unsigned)((tpi / ovec + 255) / 256);
 #define DCFP_WINO_OUT(VEC_) hipLaunchKernelGGL(wino_output_kernel<VEC_>, dim3(gout, (unsigned)N, (unsigned)M), dim3(256), 0, \
-                                               stream, Mb, pl.T, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate)
+                                               stream, Mb, pl.T16, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate)
     if (ovec == 4) DCFP_WINO_OUT(4); else if (ovec == 2) DCFP_WINO_OUT(2); else DCFP_WINO_OUT(1);
 #undef DCFP_WINO_OUT
     DCFP_RETURN_LAUNCH();
@@ -454,7 +460,7 @@ struct WinoWgradPlan { WinoPlan pl; long long T16, v, y, du, slabs; };
 WinoWgradPlan wino_wgrad_plan(int N, int H, int W, int d, int M, int C) {
     WinoWgradPlan w;
     w.pl = wino_plan(N, H, W, d, M, C);
-    w.T16 = (w.pl.T + 15) / 16 * 16;
+    w.T16 = w.pl.T16;
     w.v = align64(16LL * C * w.T16);
     w.y = align64(16LL * M * w.T16);
     w.du = align64(16LL * M * C);
@@ -478,20 +484,22 @@ size_t dcfp_wino_wgrad_workspace_bytes(int N, int H, int W, int d, int M, int C)
 
 int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, const float* x, long long x_nstride,
                         int x_pitch, float* dw, int N, int M, int C, int H, int W, int d, void* workspace,
-                        size_t workspace_bytes, hipStream_t stream) {
+                        size_t workspace_bytes, hipStream_t stream, const float* xform_in) {
     const WinoWgradPlan w = wino_wgrad_plan(N, H, W, d, M, C);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_wgrad_workspace_bytes(N, H, W, d, M, C))
         return DCFP_E_WORKSPACE;
-    float* V = static_cast<float*>(workspace);
-    float* Y = V + w.v;
+    float* Vs = static_cast<float*>(workspace);
+    const float* V = xform_in ? xform_in : Vs;
+    float* Y = Vs + w.v;
     float* dU = Y + w.y;
     float* slabs = dU + w.du;
     const int xv = wino_vec(d, W, x_pitch > 0 ? x_pitch : W, x, x_nstride, w.pl.TW);
     const int yv = wino_vec(d, W, dy_pitch > 0 ? dy_pitch : W, dy, dy_nstride, w.pl.TW);
 #define DCFP_WINO_IN(VEC_) hipLaunchKernelGGL(wino_input_kernel<VEC_>, dim3((unsigned)((w.T16 / VEC_ + 255) / 256), 1, (unsigned)C), \
                                               dim3(256), 0, stream, x, x_nstride, x_pitch > 0 ? x_pitch : W, N, C, H, W, d, \
-                                              w.pl.TH, w.pl.TW, V, w.T16)
-    if (xv == 4) DCFP_WINO_IN(4); else if (xv == 2) DCFP_WINO_IN(2); else DCFP_WINO_IN(1);
+                                              w.pl.TH, w.pl.TW, Vs, w.T16)
+    if (xform_in) { /* the forward pass left V behind */ }
+    else if (xv == 4) DCFP_WINO_IN(4); else if (xv == 2) DCFP_WINO_IN(2); else DCFP_WINO_IN(1);
 #undef DCFP_WINO_IN
 #define DCFP_WINO_DY(VEC_) hipLaunchKernelGGL(wino_dy_kernel<VEC_>, dim3((unsigned)((w.T16 / VEC_ + 255) / 256), 1, (unsigned)M), \
                                               dim3(256), 0, stream, dy, dy_nstride, dy_pitch > 0 ? dy_pitch : W, N, M, H, W, d, \
@@ -503,4 +511,10 @@ int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, con
     const long long mc = (long long)M * C;
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, stream, dU, mc, dw);
     DCFP_RETURN_LAUNCH();
+}
+
+// bytes of the transformed input V (16 x C x T16 floats) that a forward call can leave behind for the weight gradient
+size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C) {
+    const WinoPlan pl = wino_plan(N, H, W, d, 256, C);
+    return (size_t)16 * C * pl.T16 * sizeof(float);
 }

@@ -304,7 +304,10 @@ def _rp(run):
     return C.byref(run) if run is not None else None
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run=None, out=None):
+KEEP_XFORM = os.environ.get("DCFP_KEEP_XFORM", "1") not in ("0",)   # =0: weight gradients transform x again (A/B)
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run=None, out=None, keep=None):
     """y = conv2d(x, w).  With want_stats the result is (y, stats): stats = (mean, biased var) of y
     per output channel over (N, H, W) - what the BatchNorm that follows needs - taken from partials
     the conv epilogue emits, or None where the library has no fused statistics for the shape; bn_run
@@ -329,6 +332,17 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run
         _require(bias, "bias"); bias = bias.contiguous()
     L = _lib.lib()
     ws, valid = _conv_workspace(w, _lib.CONV_FWD, d)
+    if keep is not None and KEEP_XFORM and bias is None:
+        # Winograd conv whose weight gradient is Winograd too: leave the transformed input in a buffer that `keep`
+        # (a dict living in the autograd context) holds until the backward pass (conv2d_wgrad(..., xform=))
+        xb = L.dcfp_conv2d_xform_bytes(C.byref(d))
+        if xb > 0:
+            xf = torch.empty(xb, dtype=torch.uint8, device=x.device)
+            _timed("conv_fwd", d, _conv_flops(d), lambda: check(
+                L.dcfp_conv2d_fwd_keep_f32_nchw(C.byref(d), _p(x), _p(w), _p(y), yns, _p(xf), xb, _p(ws), ws.numel(),
+                                                _stream()), "conv2d_fwd_keep"))
+            keep["xform"] = xf
+            return (y, None) if want_stats else y
     if want_stats and bias is None:
         slots = L.dcfp_conv2d_fwd_stat_slots(C.byref(d), _p(y), yns)
         if slots > 0:
@@ -371,8 +385,9 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
     return dx
 
 
-def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=None):
-    """(dw, db); dw / db: optional destinations (the gradient arena's views)."""
+def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=None, xform=None):
+    """(dw, db); dw / db: optional destinations (the gradient arena's views).  xform: the transformed input the
+    forward call left behind (conv2d_fwd(..., keep=)), taken instead of x where the library says so."""
     _require(dy, "dy"); _require(x, "x")
     xp, dp = _pitch_of(x), _pitch_of(dy)
     if not xp:
@@ -384,13 +399,18 @@ def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=N
         dy, ns = _batch_strided(dy)
     L = _lib.lib()
     nbytes = L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_WGRAD)
-    ws = _workspace("wgrad", nbytes, x.device)
+    ws = _workspace("conv_scratch", nbytes, x.device)     # (shared with the forward / dgrad scratch: same stream)
     if dw is None:
         dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
     elif tuple(dw.shape) != tuple(wshape) or not dw.is_contiguous():
         raise RuntimeError("conv2d_wgrad: dw must be a contiguous tensor of the weight shape")
     if need_bias and db is None:
         db = torch.empty((wshape[0],), dtype=torch.float32, device=x.device)
+    if xform is not None and not need_bias and L.dcfp_conv2d_xform_bytes(C.byref(d)) == xform.numel():
+        _timed("conv_wgrad", d, _conv_flops(d), lambda: check(
+            L.dcfp_conv2d_wgrad_kept_f32_nchw(C.byref(d), _p(dy), ns, _p(xform), xform.numel(), _p(dw), _p(ws), ws.numel(),
+                                              _stream()), "conv2d_wgrad_kept"))
+        return dw, None
     _timed("conv_wgrad", d, _conv_flops(d), lambda: check(
         L.dcfp_conv2d_wgrad_f32_nchw(C.byref(d), _p(dy), ns, _p(x), _p(dw), _p(db) if need_bias else None, _p(ws),
                                      ws.numel(), _stream()), "conv2d_wgrad"))
@@ -402,12 +422,14 @@ def add_into(dst, src):
     check(_lib.lib().dcfp_add_f32(_p(dst), _p(src), _p(dst), dst.numel(), _stream()), "add")
 
 
-def wgrad_into_param(dy, x, w, bias, stride, pad, dil):
+def wgrad_into_param(dy, x, w, bias, stride, pad, dil, keep=None):
     """Weight (and bias) gradient of a conv written where the parameter's gradient lives: returns
-    (dw, db) as the autograd Function should return them (None = already accumulated in .grad)."""
+    (dw, db) as the autograd Function should return them (None = already accumulated in .grad).
+    keep: the dict the forward call filled (conv2d_fwd(..., keep=)); its buffer is released here."""
     tw, kw = arena.grad_target(w)
     tb, kb = arena.grad_target(bias) if bias is not None else (None, 0)
-    conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, dil, need_bias=bias is not None, dw=tw, db=tb)
+    xform = keep.pop("xform", None) if keep else None
+    conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, dil, need_bias=bias is not None, dw=tw, db=tb, xform=xform)
     dw = arena.grad_commit(w, tw, kw, add_into)
     db = arena.grad_commit(bias, tb, kb, add_into) if bias is not None else None
     return dw, db
@@ -419,7 +441,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil):
-        y = conv2d_fwd(x, w, bias, stride, pad, dil)
+        ctx.keep = {} if ctx.needs_input_grad[1] else None     # (a backward pass will ask for the weight gradient)
+        y = conv2d_fwd(x, w, bias, stride, pad, dil, keep=ctx.keep)
         ctx.save_for_backward(x)
         ctx.params = (w, bias)           # the Parameter objects: their gradient slots are looked up on them
         ctx.cfg = (stride, pad, dil)
@@ -434,7 +457,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(dy, w, tuple(x.shape), stride, pad, dil)
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
-            dw, db = wgrad_into_param(dy, x, w, bias, stride, pad, dil)
+            dw, db = wgrad_into_param(dy, x, w, bias, stride, pad, dil, keep=ctx.keep)
         return dx, dw, db, None, None, None
 
 
@@ -791,16 +814,16 @@ class BottleneckFn(torch.autograd.Function):
         stride, dil = cfg["stride"], cfg["dil"]
         fuse = FUSE_BN_STATS   # each conv hands the batch statistics of its output to the BatchNorm behind it
 
-        def conv_bn(inp, wgt, a, g, b, st=1, pd=0, dl=1, relu=True, res=None, want_mask=False, out=None):
+        def conv_bn(inp, wgt, a, g, b, st=1, pd=0, dl=1, relu=True, res=None, want_mask=False, out=None, keep=None):
             rm, rv, training, momentum, eps, sync, nbt = a
             stats = None
             if fuse and training:
                 # the kernel finalising the statistics also does the running-stat bookkeeping, unless the
                 # statistics still have to be pooled over the ranks first (SyncBN)
                 run = _bn_run(rm, rv, momentum, nbt) if _sync_group(sync) is None else None
-                c, stats = conv2d_fwd(inp, wgt, None, st, pd, dl, want_stats=True, bn_run=run)
+                c, stats = conv2d_fwd(inp, wgt, None, st, pd, dl, want_stats=True, bn_run=run, keep=keep)
             else:
-                c = conv2d_fwd(inp, wgt, None, st, pd, dl)
+                c = conv2d_fwd(inp, wgt, None, st, pd, dl, keep=keep)
             y, state = bn_forward_impl(c, g, b, rm, rv, res, relu, training, momentum, eps, sync, nbt=nbt,
                                        stats=stats, want_mask=want_mask, out=out)
             return c, y, state
@@ -817,7 +840,9 @@ class BottleneckFn(torch.autograd.Function):
             y1_out, ctx.pitch_slot = owner_pitched(cfg.get("owner"), y1_shape, pitch, x.device)
         ctx.pitch = pitch
         c1, y1, st1 = conv_bn(x, w1, bnargs[0], g1, b1, out=y1_out)
-        c2, y2, st2 = conv_bn(y1, w2, bnargs[1], g2, b2, stride, dil, dil)
+        # (conv2's Winograd input transform is kept for its weight gradient: 4x the size of y1, until this block's backward)
+        ctx.keep2 = {} if ctx.needs_input_grad[5] else None      # inputs: x, cfg, w1, g1, b1, w2, ...
+        c2, y2, st2 = conv_bn(y1, w2, bnargs[1], g2, b2, stride, dil, dil, keep=ctx.keep2)
         if has_ds:
             wd, gd, bd = tensors[9:]
             cd, res, std = conv_bn(x, wd, bnargs[3], gd, bd, stride, 0, 1, relu=False)
@@ -865,8 +890,8 @@ class BottleneckFn(torch.autograd.Function):
             return st + ((flat[pos],) if has_mask else ())
         st1, st2, st3, std = state(0), state(1), state(2), state(3)
 
-        def wg(dy, inp, w, st=1, pd=0, dl=1):
-            return lambda: wgrad_into_param(dy, inp, w, None, st, pd, dl)[0]
+        def wg(dy, inp, w, st=1, pd=0, dl=1, keep=None):
+            return lambda: wgrad_into_param(dy, inp, w, None, st, pd, dl, keep=keep)[0]
 
         # bn3 (+residual, ReLU): gradient of conv3's output and of the residual branch
         d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], True)
@@ -877,7 +902,7 @@ class BottleneckFn(torch.autograd.Function):
                                                   between=wg(d_c3, y2, w3), dx_out=dc2_out)
         d_y1 = conv2d_dgrad(d_c2, w2, tuple(y1.shape), stride, dil, dil)
         d_c1, dg1, db1, _, dw2 = bn_backward_impl(d_y1, c1, None, g1, b1, st1, True, training[0], eps[0], False,
-                                                  between=wg(d_c2, y1, w2, stride, dil, dil))
+                                                  between=wg(d_c2, y1, w2, stride, dil, dil, keep=ctx.keep2))
         grads = [None, dg1, db1, dw2, dg2, db2, dw3, dg3, db3]
         if ctx.has_ds:
             wd, gd, bd = tensors[9:]
@@ -925,17 +950,19 @@ class AsppFn(torch.autograd.Function):
         widths = [t.shape[0] for t in tensors[0::3]]
         cat = torch.empty((N, sum(widths), H, W), dtype=torch.float32, device=x.device)
         offs = [sum(widths[:k]) for k in range(5)]
-        states, cs = [], []
+        states, cs, keeps = [], [], []
         for k in range(4):
             w, g, b = tensors[3 * k:3 * k + 3]
             pad, dil = cfg["convs"][k]
             rm, rv, training, momentum, eps, sync, nbt = cfg["bn"][k]
             stats = None
+            kp = {} if ctx.needs_input_grad[2 + 3 * k] else None      # inputs: x, cfg, then (w, gamma, beta) per branch
+            keeps.append(kp)
             if FUSE_BN_STATS and training:
                 run = _bn_run(rm, rv, momentum, nbt) if _sync_group(sync) is None else None
-                c, stats = conv2d_fwd(x, w, None, 1, pad, dil, want_stats=True, bn_run=run)
+                c, stats = conv2d_fwd(x, w, None, 1, pad, dil, want_stats=True, bn_run=run, keep=kp)
             else:
-                c = conv2d_fwd(x, w, None, 1, pad, dil)
+                c = conv2d_fwd(x, w, None, 1, pad, dil, keep=kp)
             _, st = bn_forward_impl(c, g, b, rm, rv, None, True, training, momentum, eps, sync, nbt=nbt, stats=stats,
                                     out=cat[:, offs[k]:offs[k] + widths[k]])
             cs.append(c); states.append(st)
@@ -946,6 +973,7 @@ class AsppFn(torch.autograd.Function):
         y5, st5 = bn_forward_impl(c5, g5, b5, rm, rv, None, True, training, momentum, eps, sync, nbt=nbt)
         broadcast_hw(y5, H, W, out=cat[:, offs[4]:offs[4] + widths[4]])   # bilinear 1x1 -> HxW (aspp.py:76)
         states.append(st5)
+        ctx.keeps = keeps        # the branches' kept Winograd input transforms (released by their weight gradients)
         ctx.cfg = (cfg["convs"], [a[2] for a in cfg["bn"]], [a[4] for a in cfg["bn"]], offs, widths)
         ctx.params = tensors
         flat, meta = [], []
@@ -985,7 +1013,8 @@ class AsppFn(torch.autograd.Function):
                 grads[3 * (k - 1)] = res[4]
             if need_dx:
                 dx = conv2d_dgrad(d_c, w, tuple(x.shape), 1, pad, dil, out=dx, accumulate=dx is not None)
-            pending = (lambda d_c=d_c, w=w, pad=pad, dil=dil: wgrad_into_param(d_c, x, w, None, 1, pad, dil)[0])
+            pending = (lambda d_c=d_c, w=w, pad=pad, dil=dil, kp=ctx.keeps[k]:
+                       wgrad_into_param(d_c, x, w, None, 1, pad, dil, keep=kp)[0])
         # image-pooling branch: broadcast^T = sum over pixels, then BN / 1x1 conv on N x C x 1 x 1
         w5, g5, b5 = tensors[12:15]
         g_y5 = rowsum(dcat[:, offs[4]:offs[4] + widths[4]], 1.0)

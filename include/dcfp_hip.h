@@ -107,6 +107,19 @@ int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d);
  * per conv.  0: the workspace holds the permuted weight copy described under `wp_valid`. */
 int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass);
 
+/* Winograd convs (see dcfp_conv2d_workspace_is_scratch): forward and weight gradient transform the same input x
+ * the same way.  dcfp_conv2d_xform_bytes > 0: the forward call may write that transform (16 x Cin x tiles floats, 4x
+ * the size of x) into a caller-owned buffer, and the weight gradient takes it instead of x - a fifth to a quarter of
+ * its time - at the price of keeping the buffer alive between the two (the way autograd keeps x).  Same results
+ * either way (the same kernels produce the same values).  0: not available for this descriptor. */
+size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d);
+int dcfp_conv2d_fwd_keep_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y, int64_t y_nstride,
+                                  float* xform_out, size_t xform_bytes, void* workspace, size_t workspace_bytes,
+                                  dcfp_stream_t stream);
+int dcfp_conv2d_wgrad_kept_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride, const float* xform,
+                                    size_t xform_bytes, float* dw, void* workspace, size_t workspace_bytes,
+                                    dcfp_stream_t stream);
+
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
  * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the
  * string rocprofv3 shows (demangled) for the launch; used by bench.py to label rooflines.
