@@ -51,7 +51,12 @@ def _child():
         dx_slice = ops.conv2d_dgrad(dwide[:, 32:32 + Cout], wd, tuple(x.shape), 1, d, d)
         dw, _ = ops.conv2d_wgrad(dyd, xd, tuple(w.shape), 1, d, d)
         dw_slice, _ = ops.conv2d_wgrad(dwide[:, 32:32 + Cout], xd, tuple(w.shape), 1, d, d)
-        rec = {"kernels": names, "wgrad_slice_equal": bool(torch.equal(dw, dw_slice)), "slice_equal": bool(torch.equal(wide[:, 32:32 + Cout], y)),
+        # the forward call can leave its transformed input behind for the weight gradient: same y, same dw
+        kp = {}
+        y_keep = ops.conv2d_fwd(xd, wd, None, 1, d, d, keep=kp)
+        dw_keep, _ = ops.conv2d_wgrad(dyd, xd, tuple(w.shape), 1, d, d, xform=kp.get("xform"))
+        rec = {"kernels": names, "wgrad_slice_equal": bool(torch.equal(dw, dw_slice)),
+               "kept": "xform" in kp, "keep_equal": bool(torch.equal(y_keep, y) and torch.equal(dw_keep, dw)), "slice_equal": bool(torch.equal(wide[:, 32:32 + Cout], y)),
                "slice_untouched": bool((wide[:, :32] == 7.0).all() and (wide[:, 32 + Cout:] == 7.0).all()),
                "dgrad_slice_equal": bool(torch.equal(dx_slice, dx)),
                "frac": [ops.conv_executed_fraction(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)],
@@ -103,6 +108,7 @@ def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
         assert all(0.44 <= f <= 0.60 for f, v in zip(rec["frac"], want) if v), (k, rec["frac"])   # 16/36 x tile padding
         assert rec["slice_equal"] and rec["slice_untouched"] and rec["dgrad_slice_equal"] and rec["wgrad_slice_equal"], (k, rec)
         assert rec.get("pitched_equal", True), k
+        assert rec["kept"] and rec["keep_equal"] and not ref["kept"] and ref["keep_equal"], (k, rec["kept"], rec["keep_equal"])
         # the stated fp32 tolerance of the conv tests (tests/test_ops_gpu.py: 3e-6 * max(1, sqrt(K) / 8), K = 9 Cin) ...
         K = 9 * int(k.split("x")[1])
         tol = 3e-6 * max(1.0, math.sqrt(K) / 8)
