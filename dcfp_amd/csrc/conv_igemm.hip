@@ -62,7 +62,9 @@ size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck);
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out = nullptr);
+                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out = nullptr,
+                  float* stat_part = nullptr);
+long long dcfp_wino_stat_slots(int N, int H, int W, int d);
 size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
 bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d);      // conv_wgrad.hip
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
@@ -201,6 +203,8 @@ extern "C" double dcfp_conv2d_executed_fraction(const DcfpConvDesc* d, int pass)
                                            d->pad, -d->dil, pitched);
 }
 
+extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride);
+
 // Bytes of the transformed input (Winograd V, conv_winograd.hip) that the forward pass of this conv can write into a
 // caller-owned buffer (dcfp_conv2d_fwd_keep_f32_nchw) for its weight gradient to take over
 // (dcfp_conv2d_wgrad_kept_f32_nchw) instead of transforming x again; 0 where either pass is not Winograd.
@@ -211,8 +215,9 @@ extern "C" size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d) {
 }
 
 extern "C" int dcfp_conv2d_fwd_keep_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y,
-                                             int64_t y_nstride, float* xform_out, size_t xform_bytes, void* workspace,
-                                             size_t workspace_bytes, dcfp_stream_t stream) {
+                                             int64_t y_nstride, float* xform_out, size_t xform_bytes,
+                                             float* stat_partials, void* workspace, size_t workspace_bytes,
+                                             dcfp_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y || !xform_out) return DCFP_E_BADDESC;
@@ -222,7 +227,8 @@ extern "C" int dcfp_conv2d_fwd_keep_f32_nchw(const DcfpConvDesc* d, const float*
     const int T = 9;
     return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T, 0, y,
                          y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, d->H, d->W,
-                         d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), xform_out);
+                         d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), xform_out,
+                         (stat_partials && dcfp_conv2d_fwd_stat_slots(d, y, y_nstride) > 0) ? stat_partials : nullptr);
 }
 
 extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w,
@@ -254,7 +260,8 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
 // dcfp_bn_stats_from_partials_f32).  slots == 0: this shape / math mode has no fused statistics.
 extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride) {
     if (check_desc(d) != DCFP_OK) return 0;
-    if (wino_pass(d, DCFP_CONV_FWD)) return 0;      // (the output transform has no statistics epilogue)
+    if (wino_pass(d, DCFP_CONV_FWD))                // (the output transform emits them where every tile is interior)
+        return (y_nstride % 4 == 0 && dcfp_aligned16(y)) ? dcfp_wino_stat_slots(d->N, d->H, d->W, d->dil) : 0;
     if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1)) return 0;
     return dcfp_igemm2_stat_slots(d->Cout, d->Hout * d->Wout, d->N,
                                   y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, y);
@@ -269,6 +276,10 @@ extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float
     if (!x || !w || !y || !stat_partials) return DCFP_E_BADDESC;
     if (dcfp_conv2d_fwd_stat_slots(d, y, y_nstride) <= 0) return DCFP_E_UNSUPPORTED;
     const int T = d->KH * d->KW;
+    if (wino_pass(d, DCFP_CONV_FWD))
+        return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T, 0, y,
+                             y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, d->H, d->W,
+                             d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, stat_partials);
     return dcfp_igemm2_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), w, d->Cin * T, T, nullptr, y,
                            y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                            d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,

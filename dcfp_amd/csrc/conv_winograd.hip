@@ -246,10 +246,14 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 }
 
 // y[n][k][2x2 outputs of tile t] (+)= A^T m A,  m[xi] = Mb[xi][k][n * TH * TW + t].  grid (ceil(TH*TW / VEC / 256), N, K)
-template <int VEC>
+// STATS: also the BatchNorm statistics of y as partials (mean, M2) over 128 outputs each - the 32 tiles of 32 / VEC
+// neighbouring lanes - in the layout dcfp_bn_stats_from_partials_f32 merges (part[slot][k], slot = tile / 32); only
+// launched where every tile lies wholly inside the image (H, W multiples of 2 d) and tiles per image % 32 == 0.
+template <int VEC, bool STATS = false>
 __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mb, long long T, int K,
                                                           float* __restrict__ y, long long y_nstride, int H, int W,
-                                                          int d, int TH, int TW, int accumulate) {
+                                                          int d, int TH, int TW, int accumulate,
+                                                          float* __restrict__ stat_part) {
     const int tpi = TH * TW;
     const int t = (blockIdx.x * 256 + threadIdx.x) * VEC;
     if (t >= tpi) return;
@@ -265,6 +269,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 #pragma unroll
         for (int s = 0; s < 4; ++s) vload<VEC>(src + (4 * r + s) * plane, m[r][s]);
     float* dst = y + (long long)n * y_nstride + (long long)k * H * W;
+    float keep_o[2][2][VEC];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int h = ho + r * d;
@@ -280,6 +285,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
         for (int v = 0; v < VEC; ++v) {
             o[0][v] = (u[0][v] + u[1][v]) + u[2][v];
             o[1][v] = (u[1][v] - u[2][v]) - u[3][v];
+            if constexpr (STATS) { keep_o[r][0][v] = o[0][v]; keep_o[r][1][v] = o[1][v]; }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -298,6 +304,33 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                 for (int v = 0; v < VEC; ++v)
                     if (ww + v < W) e[v] = accumulate ? e[v] + o[s][v] : o[s][v];
             }
+        }
+    }
+    if constexpr (STATS) {
+        constexpr int G = 32 / VEC;                 // lanes per partial (32 tiles, 128 outputs)
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sum += keep_o[r][s2][v];
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum * (1.0f / 128.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { const float dd = keep_o[r][s2][v] - mean; m2 += dd * dd; }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, 64);
+        if ((threadIdx.x & (G - 1)) == 0) {
+            const long long slot = ((long long)n * tpi + t) >> 5;
+            float* sp = stat_part + (slot * K + k) * 2;
+            sp[0] = mean; sp[1] = m2;
         }
     }
 }
@@ -406,11 +439,20 @@ double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck) {
 }
 
 // in: x (forward) or dy (dgrad), rows at `in_pitch` floats; w with strides (sAm, sAc) as dcfp_igemm2_run takes them
+// Partials (of 128 outputs each) per channel that the output transform can emit for the BatchNorm behind the conv; 0 where
+// some tile is not wholly inside the image
+long long dcfp_wino_stat_slots(int N, int H, int W, int d) {
+    if (H % (2 * d) != 0 || W % (2 * d) != 0 || (W / 2) % 4 != 0) return 0;
+    const long long tpi = (long long)(H / 2) * (W / 2);
+    if (tpi % 32 != 0) return 0;
+    return (long long)N * tpi / 32;
+}
+
 // xform_out (nullable): 16 * Ck * T16 floats of the caller's that receive the transformed input V instead of the scratch
 // (the weight gradient of the same conv can take it over: dcfp_wino_wgrad_run's xform_in)
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out) {
+                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part) {
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
         return DCFP_E_WORKSPACE;
@@ -439,9 +481,12 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     if (rc) return rc;
     const int ovec = wino_vec(d, W, W, out, out_nstride, pl.TW);
     const unsigned gout = (unsigned)((tpi / ovec + 255) / 256);
-#define DCFP_WINO_OUT(VEC_) hipLaunchKernelGGL(wino_output_kernel<VEC_>, dim3(gout, (unsigned)N, (unsigned)M), dim3(256), 0, \
-                                               stream, Mb, pl.T16, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate)
-    if (ovec == 4) DCFP_WINO_OUT(4); else if (ovec == 2) DCFP_WINO_OUT(2); else DCFP_WINO_OUT(1);
+#define DCFP_WINO_OUT(VEC_, ST_) hipLaunchKernelGGL((wino_output_kernel<VEC_, ST_>), dim3(gout, (unsigned)N, (unsigned)M), dim3(256), 0, \
+                                               stream, Mb, pl.T16, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate, stat_part)
+    if (stat_part) {
+        if (!dcfp_wino_stat_slots(N, H, W, d) || accumulate) return DCFP_E_UNSUPPORTED;
+        if (ovec == 4) DCFP_WINO_OUT(4, true); else if (ovec == 2) DCFP_WINO_OUT(2, true); else DCFP_WINO_OUT(1, true);
+    } else if (ovec == 4) DCFP_WINO_OUT(4, false); else if (ovec == 2) DCFP_WINO_OUT(2, false); else DCFP_WINO_OUT(1, false);
 #undef DCFP_WINO_OUT
     DCFP_RETURN_LAUNCH();
 }

@@ -338,10 +338,17 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run
         xb = L.dcfp_conv2d_xform_bytes(C.byref(d))
         if xb > 0:
             xf = torch.empty(xb, dtype=torch.uint8, device=x.device)
+            slots = L.dcfp_conv2d_fwd_stat_slots(C.byref(d), _p(y), yns) if want_stats else 0
+            part = _workspace("bn_stat_partials", slots * d.Cout * 2 * 4, x.device) if slots > 0 else None
             _timed("conv_fwd", d, _conv_flops(d), lambda: check(
-                L.dcfp_conv2d_fwd_keep_f32_nchw(C.byref(d), _p(x), _p(w), _p(y), yns, _p(xf), xb, _p(ws), ws.numel(),
-                                                _stream()), "conv2d_fwd_keep"))
+                L.dcfp_conv2d_fwd_keep_f32_nchw(C.byref(d), _p(x), _p(w), _p(y), yns, _p(xf), xb, _p(part), _p(ws),
+                                                ws.numel(), _stream()), "conv2d_fwd_keep"))
             keep["xform"] = xf
+            if part is not None:
+                mv = torch.empty((2, d.Cout), dtype=torch.float32, device=x.device)
+                check(L.dcfp_bn_stats_from_partials_f32(_p(part), slots, 128, d.Cout, _p(mv[0]), _p(mv[1]),
+                                                        _rp(bn_run), _stream()), "bn_stats_from_partials")
+                return y, (mv[0], mv[1], bn_run is not None)
             return (y, None) if want_stats else y
     if want_stats and bias is None:
         slots = L.dcfp_conv2d_fwd_stat_slots(C.byref(d), _p(y), yns)

@@ -114,8 +114,10 @@ int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass);
  * either way (the same kernels produce the same values).  0: not available for this descriptor. */
 size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d);
 int dcfp_conv2d_fwd_keep_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y, int64_t y_nstride,
-                                  float* xform_out, size_t xform_bytes, void* workspace, size_t workspace_bytes,
-                                  dcfp_stream_t stream);
+                                  float* xform_out, size_t xform_bytes,
+                                  float* stat_partials /* nullable: as dcfp_conv2d_fwd_stats_f32_nchw, where
+                                                          dcfp_conv2d_fwd_stat_slots > 0 */,
+                                  void* workspace, size_t workspace_bytes, dcfp_stream_t stream);
 int dcfp_conv2d_wgrad_kept_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride, const float* xform,
                                     size_t xform_bytes, float* dw, void* workspace, size_t workspace_bytes,
                                     dcfp_stream_t stream);
