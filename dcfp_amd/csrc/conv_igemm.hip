@@ -115,7 +115,8 @@ static bool wino_pass(const DcfpConvDesc* d, int pass) {
     const double nominal = 2.0 * d->N * (double)d->H * d->W * (double)M * Ck * 9.0;
     const double f_direct = fwd ? dcfp_igemm2_exec_fraction(9, M, Ck, d->N, d->H, d->W, d->H, d->W, 1, 1, -d->pad, d->dil, pitched)
                                 : dcfp_igemm2_exec_fraction(9, M, Ck, d->N, d->H, d->W, d->H, d->W, 1, 1, d->pad, -d->dil, pitched);
-    const double t_direct = nominal * f_direct / 143e12;
+    // (channel counts off the 256 grid - pruned models - run the ragged-M direct kernel: 100...127 TF measured)
+    const double t_direct = nominal * f_direct / (M % 256 != 0 ? 115e12 : 143e12);
     const double f_wino = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, M, Ck);
     const double tiles = f_wino * 9.0 / 16.0 * d->N * (double)d->H * d->W;          // T
     // batched GEMM rate by shape class (measured): K = 256 is store-bound (118 TF at M = 256, 130 at M >= 1024),
@@ -124,7 +125,8 @@ static bool wino_pass(const DcfpConvDesc* d, int pass) {
     const double pix = (double)d->N * d->H * d->W;
     const double t_in = (4.0 * pix * Ck + 64.0 * tiles * Ck) / 4.2e12;
     const double t_out = (64.0 * tiles * M + 4.0 * pix * M * (fwd ? 1.0 : 2.0)) / 5.4e12;
-    const double t_wino = nominal * f_wino / rate + t_in + t_out + 20e-6;
+    const double mpad = (double)((M + 255) / 256 * 256) / M;      // the GEMM's tiles are 256 (128) rows: ragged M pays for the padding
+    const double t_wino = nominal * f_wino * mpad / rate + t_in + t_out + 20e-6;
     return t_wino < 0.97 * t_direct;
 }
 

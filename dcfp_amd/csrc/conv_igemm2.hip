@@ -1164,8 +1164,8 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
     const bool plain = !scale && !relu && !stat_part;     // (bias is handled by the ragged-M kernel's epilogue)
-    const bool d8 = plain && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo,
-                                                  in_pitch > 0 && in_pitch != Wi);
+    const bool d8 = plain && !wp_nstride && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo,
+                                                                 in_pitch > 0 && in_pitch != Wi);
     if (d8) p.Mpad = round_up(M, 256);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
     p.in_pitch = in_pitch > 0 ? in_pitch : Wi;

@@ -894,7 +894,10 @@ int dcfp_wgrad_batched_run(const float* a, const float* bmat, float* out, int ba
     p.batch = batch; p.dy_bstride = (long long)M * K; p.x_bstride = (long long)C * K;
     const long long blocks = (long long)p.tiles_m * p.tiles_n * splits * batch;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
-    int rc = launch_dma<1, false, false, true>(p, blocks, stream);
+    // ragged M (pruned widths): the 8 x 2 wave layout skips the dead 32-row blocks of the last M tile
+    const long long mp = (long long)p.tiles_m * 256, live = (long long)((M + 31) / 32) * 32;
+    int rc = (M % 256 != 0 && 10 * live <= 9 * mp) ? launch_dma<1, false, true, true>(p, blocks, stream)
+                                                   : launch_dma<1, false, false, true>(p, blocks, stream);
     if (rc) return rc;
     if (splits > 1) {
         const long long wn = (long long)batch * M * C;
@@ -950,10 +953,14 @@ static bool wino_wgrad_pass(const DcfpConvDesc* d) {
     const double pix = (double)d->N * d->H * d->W;
     const double nominal = 2.0 * pix * d->Cout * (double)d->Cin * 9.0;
     const bool dense_d1 = wgrad_dma_mixed(d) && !(d->x_pitch && d->x_pitch != d->W);
-    const double t_direct = nominal / (dense_d1 ? 123e12 : 130e12);
+    const bool ragged = d->Cout % 256 != 0 || (d->Cin * 9) % 256 != 0;      // the direct kernel pays for its tile padding too
+    const double dpad = ragged ? (double)((d->Cout + 31) / 32 * 32) / d->Cout * (double)((d->Cin * 9 + 255) / 256 * 256) / (d->Cin * 9) * 1.15
+                               : 1.0;     // (x 1.15: the 8 x 2 wave layout of the ragged-M kernel)
+    const double t_direct = nominal * dpad / (dense_d1 ? 123e12 : 130e12);
     const double f = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
     const double tiles = f * 9.0 / 16.0 * pix;
-    const double t_wino = nominal * f / 125e12 + (4.0 * pix * d->Cin + 64.0 * tiles * d->Cin) / 4.2e12 +
+    const double pad2 = (double)((d->Cout + 255) / 256 * 256) / d->Cout * (double)((d->Cin + 255) / 256 * 256) / d->Cin;
+    const double t_wino = nominal * f * pad2 / 125e12 + (4.0 * pix * d->Cin + 64.0 * tiles * d->Cin) / 4.2e12 +
                           (4.0 * pix * d->Cout + 64.0 * tiles * d->Cout) / 5.0e12 + 30e-6;
     return t_wino < 0.97 * t_direct;
 }

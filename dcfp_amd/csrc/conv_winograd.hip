@@ -417,13 +417,14 @@ static int wino_vec(int d, int W, int pitch, const float* base, long long nstrid
 // 3x3, stride 1, pad == dil, same-size output; M = output channels of the pass, Ck = reduced channels
 bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck) {
     if (!dcfp_igemm2_persist()) return false;
-    if (M < 256 || Ck < 256) return false;                       // the transforms cost ~ 1/M + 1/Ck of the GEMM
+    if (M < 129 || Ck < 128) return false;     // the transforms cost ~ 1/M + 1/Ck of the GEMM (the cost model decides)
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (4 * pl.T > (long long)N * H * W * 27 / 20) return false;  // > 35 % padding of the 2d x 2d super-blocks
     if (pl.T16 >= (1LL << 26) || 16LL * pl.T16 >= (1LL << 30)) return false;
     if ((long long)Ck * pl.T16 >= (1LL << 29) || (long long)M * pl.T16 >= (1LL << 29)) return false;
     const int P = (int)pl.T16;
-    if (dcfp_igemm2_use_dma8(1, M, P, 16LL * P, 1, 1, 0, 1, P, P, false)) return false;
+    // (ragged M - pruned models - runs on the persistent kernel's edge tiles: the batched GEMM never takes the
+    //  ragged-M kernel, whose permuted weight layout has no per-image copies)
     return dcfp_igemm2_dma_shape(1, M, Ck, P, 16LL * P, 1, 1, 0, P, P);
 }
 
@@ -515,7 +516,7 @@ WinoWgradPlan wino_wgrad_plan(int N, int H, int W, int d, int M, int C) {
 }  // namespace
 
 bool dcfp_wino_wgrad_ok(int N, int H, int W, int d, int M, int C) {
-    if (M < 256 || C < 256) return false;
+    if (M < 128 || C < 128) return false;
     const WinoWgradPlan w = wino_wgrad_plan(N, H, W, d, M, C);
     if (4 * w.pl.T > (long long)N * H * W * 27 / 20) return false;
     if (w.T16 >= (1LL << 30) || (long long)M * w.T16 >= (1LL << 29) || (long long)C * w.T16 >= (1LL << 29)) return false;

@@ -100,8 +100,8 @@ def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
     assert wino.keys() == direct.keys() and len(wino) == len(SHAPES)
     for k, rec in wino.items():
         ref = direct[k]
-        # (a pass whose output-channel count is off the 256 grid stays on the ragged-M direct kernel: 288-channel dgrad)
-        want = [True, int(k.split("x")[1]) % 256 == 0, True]
+        # (every pass, also the 288-channel dgrad off the 256 grid: the batched GEMM pads M on its edge tiles)
+        want = [True, True, True]
         assert [n.startswith("winograd_f2x2_3x3") for n in rec["kernels"]] == want, (k, rec["kernels"])
         assert not any(n.startswith("winograd") for n in ref["kernels"]), (k, ref["kernels"])
         assert rec["scratch"] == [int(v) for v in want[:2]] and ref["scratch"] == [0, 0]
