@@ -702,7 +702,13 @@ Plan make_plan(const DcfpConvDesc* d) {
     // 65 vs 91 TF on the 64-channel 3x3 convs, 61 vs 65 TF on 256->64 1x1 - and is not used.)
     static const bool lopsided = [] { const char* e = getenv("DCFP_WGRAD_LOPSIDED"); return !e || atoi(e) != 0; }();   // =0: off
     if (M > 128 && Nn > 128) { pl.cfg = 0; pl.bm = 256; pl.bn = 256; }
-    else if (M > 64 && Nn > 128) { pl.cfg = 1; pl.bm = 128; pl.bn = 256; }
+    else if (M > 64 && Nn > 128) {
+        pl.cfg = 1; pl.bm = 128; pl.bn = 256;
+        // 128 x 192 where that pads the (channel, tap) columns less: 64 -> 128 3x3 has 576 = 3 x 192 of them (768 on
+        // 256-column tiles: a quarter of the MFMAs on padding), 128 -> 128 has 1152 = 6 x 192 (1280)
+        static const bool t192 = [] { const char* e = getenv("DCFP_WGRAD_T192"); return !e || atoi(e) != 0; }();   // =0: off
+        if (t192 && (Nn + 191) / 192 * 192 < (Nn + 255) / 256 * 256) { pl.cfg = 5; pl.bn = 192; }
+    }
     else if (lopsided && M > 128 && Nn > 64) { pl.cfg = 3; pl.bm = 256; pl.bn = 128; }
     else if (lopsided && M > 128 && Nn > 32) { pl.cfg = 4; pl.bm = 256; pl.bn = 64; }
     else { pl.cfg = 2; pl.bm = 64; pl.bn = 64; }
@@ -730,7 +736,7 @@ Plan make_plan(const DcfpConvDesc* d) {
     // count wastes most of a round (513 blocks on 256 CUs took 1.35x the time of 252).
     const int cus = num_cus();
     // resident workgroups per CU (accumulator registers per lane: 256 / 128 / 64 / 32)
-    const long long per_cu = pl.cfg == 2 ? 8 : pl.cfg == 0 ? 1 : 2;
+    const long long per_cu = pl.cfg == 2 ? 8 : pl.cfg == 0 ? 1 : 2;      // (cfg 5: 96 accumulator registers, 51 KB LDS: 2)
     const long long slots = (long long)cus * per_cu;
     const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);   // >= 8 K-steps per split
     long long splits = 1;
@@ -830,6 +836,7 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
         case 1: return launch_cfg<TAPS, 2, 4, 2, 2>(p, blocks, stream);
         case 3: return launch_cfg<TAPS, 4, 2, 2, 2>(p, blocks, stream);
         case 4: return launch_cfg<TAPS, 4, 1, 2, 2>(p, blocks, stream);
+        case 5: return launch_cfg<TAPS, 2, 3, 2, 2>(p, blocks, stream);
         default: return launch_cfg<TAPS, 2, 2, 1, 1>(p, blocks, stream);
     }
 }
@@ -921,7 +928,7 @@ int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
     if (wino_wgrad_pass(d)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false,false,true>)");
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
-                       pl.cfg == 4 ? "4,1,2,2" : "2,2,1,1";
+                       pl.cfg == 4 ? "4,1,2,2" : pl.cfg == 5 ? "2,3,2,2" : "2,2,1,1";
     if (wgrad3_ok(d, pl.cfg)) return snprintf(buf, buf_len, "wgrad3_kernel<%d>", d->KH * d->KW);
     if (pl.wide) return snprintf(buf, buf_len, "wgrad_dma_kernel<%d,false,true>", d->KH * d->KW);
     if (wgrad_dma_ok(d, pl.cfg))
