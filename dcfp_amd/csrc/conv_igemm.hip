@@ -63,7 +63,8 @@ double dcfp_wino_exec_fraction(int N, int H, int W, int d, int M, int Ck);
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
                   void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out = nullptr,
-                  float* stat_part = nullptr);
+                  float* stat_part = nullptr, const float* scale = nullptr, const float* shift = nullptr,
+                  const float* residual = nullptr, int relu = 0);
 long long dcfp_wino_stat_slots(int N, int H, int W, int d);
 size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
 bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d);      // conv_wgrad.hip
@@ -325,6 +326,10 @@ extern "C" int dcfp_conv2d_fwd_fused_f32_nchw(const DcfpConvDesc* d, const float
     if (rc) return rc;
     if (!x || !w || !y || !scale || !shift) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (wino_pass(d, DCFP_CONV_FWD))      // the folded BatchNorm (+residual) (+ReLU) rides on the Winograd output transform
+        return dcfp_wino_run(x, (long long)d->Cin * d->H * d->W, 0, w, d->Cin * T, T, 0, y,
+                             (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, d->H, d->W, d->dil, 0, workspace,
+                             workspace_bytes, dcfp_s(stream), nullptr, nullptr, scale, shift, residual, relu ? 1 : 0);
     if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))   // opt-in bf16x3 inference
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, nullptr, y,
                                (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, T, d->H, d->W,

@@ -253,7 +253,9 @@ template <int VEC, bool STATS = false>
 __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mb, long long T, int K,
                                                           float* __restrict__ y, long long y_nstride, int H, int W,
                                                           int d, int TH, int TW, int accumulate,
-                                                          float* __restrict__ stat_part) {
+                                                          float* __restrict__ stat_part,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ residual, int relu) {
     const int tpi = TH * TW;
     const int t = (blockIdx.x * 256 + threadIdx.x) * VEC;
     if (t >= tpi) return;
@@ -269,6 +271,9 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 #pragma unroll
         for (int s = 0; s < 4; ++s) vload<VEC>(src + (4 * r + s) * plane, m[r][s]);
     float* dst = y + (long long)n * y_nstride + (long long)k * H * W;
+    // inference: eval-mode BatchNorm folded into the epilogue, y = act(conv * scale[k] + shift[k] (+ residual))
+    const float sc = scale ? scale[k] : 1.f, sf = scale ? shift[k] : 0.f;
+    const float* rsd = residual ? residual + (long long)n * y_nstride + (long long)k * H * W : nullptr;
     float keep_o[2][2][VEC];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -291,6 +296,14 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
         for (int s = 0; s < 2; ++s) {
             const int ww = wo + s * d;
             float* e = dst + (long long)h * W + ww;
+            if (scale) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float t = fmaf(o[s][v], sc, sf);
+                    if (rsd && ww + v < W) t += rsd[(long long)h * W + ww + v];
+                    o[s][v] = relu ? (t > 0.f ? t : 0.f) : t;
+                }
+            }
             if (ww + VEC <= W) {
                 if (accumulate) {
                     float old[VEC];
@@ -453,7 +466,8 @@ long long dcfp_wino_stat_slots(int N, int H, int W, int d) {
 // (the weight gradient of the same conv can take it over: dcfp_wino_wgrad_run's xform_in)
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part) {
+                  void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
+                  const float* scale, const float* shift, const float* residual, int relu) {
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
         return DCFP_E_WORKSPACE;
@@ -483,7 +497,7 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     const int ovec = wino_vec(d, W, W, out, out_nstride, pl.TW);
     const unsigned gout = (unsigned)((tpi / ovec + 255) / 256);
 #define DCFP_WINO_OUT(VEC_, ST_) hipLaunchKernelGGL((wino_output_kernel<VEC_, ST_>), dim3(gout, (unsigned)N, (unsigned)M), dim3(256), 0, \
-                                               stream, Mb, pl.T16, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate, stat_part)
+                                               stream, Mb, pl.T16, M, out, out_nstride, H, W, d, pl.TH, pl.TW, accumulate, stat_part, scale, shift, residual, relu)
     if (stat_part) {
         if (!dcfp_wino_stat_slots(N, H, W, d) || accumulate) return DCFP_E_UNSUPPORTED;
         if (ovec == 4) DCFP_WINO_OUT(4, true); else if (ovec == 2) DCFP_WINO_OUT(2, true); else DCFP_WINO_OUT(1, true);

@@ -1359,7 +1359,10 @@ def conv2d_fused_infer(x, w, scale, shift, stride=1, pad=0, dil=1, residual=None
         if tuple(residual.shape) != tuple(y.shape):
             raise RuntimeError("conv2d_fused_infer: residual shape mismatch")
     L = _lib.lib()
-    ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), "fused")
+    if L.dcfp_conv2d_workspace_is_scratch(C.byref(d), _lib.CONV_FWD):
+        ws, valid = _workspace("conv_scratch", L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), x.device), 0
+    else:
+        ws, valid = _wp_buffer(w, _lib.CONV_FWD, d, L.dcfp_conv2d_workspace_bytes(C.byref(d), _lib.CONV_FWD), "fused")
     check(L.dcfp_conv2d_fwd_fused_f32_nchw(C.byref(d), _p(x), _p(w), _p(scale.contiguous()),
                                            _p(shift.contiguous()), _p(residual), int(bool(relu)), _p(y),
                                            _p(ws), ws.numel(), valid, _stream()), "conv2d_fwd_fused")
