@@ -70,8 +70,21 @@ def _child():
             rec["pitched_equal"] = bool(torch.equal(ops.conv2d_fwd(xp, wd, None, 1, d, d), y) and
                                         torch.equal(ops.conv2d_dgrad(dyp, wd, tuple(x.shape), 1, d, d), dx) and
                                         torch.equal(ops.conv2d_wgrad(dyp, xp, tuple(w.shape), 1, d, d)[0], dw))
+        # fused statistics (where every tile is interior) against the separate statistics kernel on the same y
+        y_s, st = ops.conv2d_fwd(xd, wd, None, 1, d, d, want_stats=True)
+        rec["stats_equal_y"] = bool(torch.equal(y_s, y))
+        if st is not None:
+            m_ref, v_ref = ops.bn_stats(y)
+            rec["stats_err"] = [float((st[0] - m_ref).abs().max() / m_ref.abs().max()),
+                                float(((st[1] - v_ref).abs() / v_ref).max())]
+        # inference: eval-mode BatchNorm (+residual) (+ReLU) folded into the op's epilogue
+        sc = (torch.rand(Cout, generator=g) + 0.5).to(dev); sh = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        rs = torch.randn(N, Cout, H, W, generator=g).to(dev)
+        yf = ops.conv2d_fused_infer(xd, wd, sc, sh, 1, d, d, rs, True)
         torch.cuda.synchronize()
         ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+        reff = torch.relu(ref * sc.cpu().double()[None, :, None, None] + sh.cpu().double()[None, :, None, None] + rs.cpu().double())
+        rec["fused_infer_max"] = float((yf.cpu().double() - reff).abs().max() / reff.abs().max())
         refdx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
         refdw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, d, d)
 
@@ -98,6 +111,7 @@ def _run(mode):
 def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
     wino, direct = _run("2"), _run("0")
     assert wino.keys() == direct.keys() and len(wino) == len(SHAPES)
+    assert any("stats_err" in r for r in wino.values())          # the statistics epilogue of the output transform ran
     for k, rec in wino.items():
         ref = direct[k]
         # (every pass, also the 288-channel dgrad off the 256 grid: the batched GEMM pads M on its edge tiles)
@@ -109,6 +123,9 @@ def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
         assert rec["slice_equal"] and rec["slice_untouched"] and rec["dgrad_slice_equal"] and rec["wgrad_slice_equal"], (k, rec)
         assert rec.get("pitched_equal", True), k
         assert rec["kept"] and rec["keep_equal"] and not ref["kept"] and ref["keep_equal"], (k, rec["kept"], rec["keep_equal"])
+        assert rec["stats_equal_y"] and rec["fused_infer_max"] < 3e-6, (k, rec["fused_infer_max"])
+        if "stats_err" in rec:
+            assert rec["stats_err"][0] < 2e-5 and rec["stats_err"][1] < 2e-5, (k, rec["stats_err"])
         # the stated fp32 tolerance of the conv tests (tests/test_ops_gpu.py: 3e-6 * max(1, sqrt(K) / 8), K = 9 Cin) ...
         K = 9 * int(k.split("x")[1])
         tol = 3e-6 * max(1.0, math.sqrt(K) / 8)
