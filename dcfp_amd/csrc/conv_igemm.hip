@@ -55,7 +55,8 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale = nullptr, const float* shift = nullptr,
                     const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0,
-                    int in_pitch = 0, long long wp_nstride = 0);
+                    int in_pitch = 0, long long wp_nstride = 0, const float* fan_src = nullptr,
+                    const unsigned long long* fan_mask = nullptr);
 // conv_winograd.hip
 bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck);
 size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
@@ -314,6 +315,32 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
                            d->Cout, T, d->Hout, d->Wout, d->H, d->W, 1, d->stride, d->pad, -d->dil,
                            accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0,
                            nullptr, wp_valid, d->dy_pitch);
+}
+
+// Gradient fan-in of a residual block (resnet.py:52-56 backward): dx = dgrad(dy) + fan_src * mask, where mask is the 1-bit
+// ReLU mask of dcfp_bn_apply_relu_mask_f32 and fan_src the gradient that arrived at the block's output - the residual
+// branch's gradient is never written.  1x1 stride-1 convs on the persistent LDS-DMA kernel, Cin % 256 == 0,
+// H * W % 256 == 0 (dcfp_conv2d_dgrad_fanin_supported); fan_src has dx's layout.
+extern "C" int dcfp_conv2d_dgrad_fanin_supported(const DcfpConvDesc* d) {
+    if (check_desc(d) != DCFP_OK || d->KH != 1 || d->stride != 1 || d->pad != 0 || math_bf16x3()) return 0;
+    const int P = d->H * d->W;
+    const long long px = (long long)d->N * P;
+    if (d->Cin % 256 != 0 || P % 256 != 0 || !dcfp_igemm2_persist()) return 0;
+    if (igemm3_ok(d->Cin, px, 1, 1)) return 0;
+    return dcfp_igemm2_dma_shape(1, d->Cin, d->Cout, P, px, 1, 1, 0, P, d->W) ? 1 : 0;
+}
+
+extern "C" int dcfp_conv2d_dgrad_fanin_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride, const float* w,
+                                                float* dx, const float* fan_src, const void* fan_mask, void* workspace,
+                                                size_t workspace_bytes, int wp_valid, dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !w || !dx || !fan_src || !fan_mask) return DCFP_E_BADDESC;
+    if (!dcfp_conv2d_dgrad_fanin_supported(d)) return DCFP_E_UNSUPPORTED;
+    return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w, 1, d->Cin, nullptr, dx,
+                           (long long)d->Cin * d->H * d->W, d->N, d->Cin, d->Cout, 1, d->Hout, d->Wout, d->H, d->W, 1, 1, 0, -1,
+                           0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0, nullptr, wp_valid, 0, 0,
+                           fan_src, static_cast<const unsigned long long*>(fan_mask));
 }
 
 // Inference: conv + folded eval-mode BatchNorm (+residual) (+ReLU) in the conv epilogue.

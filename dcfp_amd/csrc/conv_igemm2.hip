@@ -1153,18 +1153,20 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int Hi, int Wi, int Ho, int Wo, int sn, int sd, int off0, int offstep,
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale, const float* shift, const float* residual, int relu,
-                    float* stat_part, int wp_valid, int in_pitch, long long wp_nstride) {
+                    float* stat_part, int wp_valid, int in_pitch, long long wp_nstride, const float* fan_src,
+                    const unsigned long long* fan_mask) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
     p.stat_part = stat_part;
     p.wp_nstride = wp_nstride;
+    p.fan_src = fan_src; p.fan_mask = fan_mask;
     p.in = in; p.bias = bias; p.out = out;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;
     p.N = N; p.M = M; p.Ck = Ck; p.CkP = round_up(Ck, ck_pad()); p.Mpad = round_up(M, c.bm);
     const bool plain = !scale && !relu && !stat_part;     // (bias is handled by the ragged-M kernel's epilogue)
-    const bool d8 = plain && !wp_nstride && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo,
+    const bool d8 = plain && !wp_nstride && !fan_src && dcfp_igemm2_use_dma8(T, M, Ho * Wo, px, sn, sd, off0, offstep, Hi * Wi, Wo,
                                                                  in_pitch > 0 && in_pitch != Wi);
     if (d8) p.Mpad = round_up(M, 256);
     p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.P = Ho * Wo;
@@ -1214,7 +1216,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                            Ck, p.CkP, M, p.Mpad, sAm, sAc, d8 ? 1 : 0);
     }
     if (d8) {
-        if (!p.vec_store || wp_nstride) return DCFP_E_UNSUPPORTED;
+        if (!p.vec_store || wp_nstride || fan_src) return DCFP_E_UNSUPPORTED;
         return dcfp_igemm2n_launch(p, T, stream);
     }
     if (dcfp_igemm2_dma_shape(T, M, Ck, p.P, px, sn, sd, off0, Hi * Wi, Wo) && p.vec_store && !bias && !scale &&
@@ -1231,6 +1233,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
             DCFP_RETURN_LAUNCH();
         };
         if (T == 1) {
+            if (fan_src && (M % 256 != 0 || p.P % 256 != 0 || !dcfp_igemm2_persist())) return DCFP_E_UNSUPPORTED;
             if (dcfp_igemm2_persist()) return dcfp_igemm2p_launch(p, stream);
             if (wp_nstride) return DCFP_E_UNSUPPORTED;
             return accumulate ? launch(igemm2_dma_kernel<1, false, true>) : launch(igemm2_dma_kernel<1, false, false>);
@@ -1239,7 +1242,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
             return accumulate ? launch(igemm2_dma_kernel<9, false, true>) : launch(igemm2_dma_kernel<9, false, false>);
         return accumulate ? launch(igemm2_dma_kernel<9, true, true>) : launch(igemm2_dma_kernel<9, true, false>);
     }
-    if (wp_nstride) return DCFP_E_UNSUPPORTED;     // per-image weights exist on the persistent 1x1 kernel only
+    if (wp_nstride || fan_src) return DCFP_E_UNSUPPORTED;     // per-image weights / masked fan-in: the persistent 1x1 kernel only
     return T == 1 ? launch_taps<1>(p, c.id, stream) : launch_taps<9>(p, c.id, stream);
 }
 

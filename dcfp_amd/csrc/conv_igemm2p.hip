@@ -48,7 +48,9 @@ constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, 
 // a kernel instance of its own so that profiles tell it from the 1x1 convs
 // TM_ = 2: 128 x 256 tiles, 128 accumulator registers per lane - TWO workgroups per CU, so that one's epilogue
 // stores and barrier waits overlap the other's MFMAs (the K = 256 layers, whose 256 x 256 tiles are store-bound).
-template <bool ACC, bool WPI = false, int TM_ = 4>
+// FAN: out = result + (mask bit ? fan_src : 0) - the block-input gradient of a Bottleneck without materialising the
+// residual branch's gradient (dy * ReLU mask): the BatchNorm backward then skips that 4 B/element write
+template <bool ACC, bool WPI = false, int TM_ = 4, bool FAN = false>
 __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles, int dbg) {
     constexpr int TM = TM_, TN = 4, WN = 2, BM = 64 * TM_, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -285,6 +287,47 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
             unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
             asm volatile("" : "+v"(voff));
             const unsigned P4 = (unsigned)p.P * 4u;
+            if constexpr (FAN) {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.fan_src) + (long long)img * p.out_nstride + (long long)m0 * p.P + p0, 0, 0x7ffffffcu,
+                    0x00020000);
+                const int words = p.P >> 6;
+                // mask words of this lane's first row; element e of a row sits in word 4 * (e >> 8) + (e & 3), bit (e & 255) >> 2
+                const unsigned long long* mrow = p.fan_mask +
+                    ((long long)img * p.M + m0 + wm * (TM * 32) + TM * 4 * lhi) * words + 4 * (p0 >> 8);
+                const int bit = wn * 32 + l31;
+                static_for<0, TM>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    static_for<0, 4>([&](auto g_) {          // four rows at a time (registers)
+                        constexpr int g4 = decltype(g_)::value;
+                        f32x4 src[4];
+                        u64x2 ma[4], mb[4];
+                        static_for<0, 4>([&](auto q_) {
+                            constexpr int r = 4 * g4 + decltype(q_)::value;
+                            constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                            src[r & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                f_rsrc, voff, (unsigned)row * P4, 0));
+                            const u64x2* mq = reinterpret_cast<const u64x2*>(mrow + (long long)row * words);
+                            ma[r & 3] = mq[0]; mb[r & 3] = mq[1];
+                        });
+                        static_for<0, 4>([&](auto q_) {
+                            constexpr int r = 4 * g4 + decltype(q_)::value;
+                            constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
+                            f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                            const f32x4 s4 = src[r & 3];
+                            v[0] += ((ma[r & 3][0] >> bit) & 1ull) ? s4[0] : 0.f;
+                            v[1] += ((ma[r & 3][1] >> bit) & 1ull) ? s4[1] : 0.f;
+                            v[2] += ((mb[r & 3][0] >> bit) & 1ull) ? s4[2] : 0.f;
+                            v[3] += ((mb[r & 3][1] >> bit) & 1ull) ? s4[3] : 0.f;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                                __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                o_rsrc, voff + (unsigned)row * P4, 0, 0);
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            } else
             static_for<0, TM>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 f32x4 old[16];
@@ -354,6 +397,10 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
     if (p.wp_nstride) {
         if (p.accumulate) return DCFP_E_UNSUPPORTED;
         return half ? launch(igemm2_dma1p_kernel<false, true, 2>) : launch(igemm2_dma1p_kernel<false, true>);
+    }
+    if (p.fan_src) {      // interior tiles only (checked by the caller: M % 256 == 0, P % 256 == 0)
+        if (p.accumulate || p.stat_part || !p.fan_mask) return DCFP_E_UNSUPPORTED;
+        return half ? launch(igemm2_dma1p_kernel<false, false, 2, true>) : launch(igemm2_dma1p_kernel<false, false, 4, true>);
     }
     if (half) return p.accumulate ? launch(igemm2_dma1p_kernel<true, false, 2>) : launch(igemm2_dma1p_kernel<false, false, 2>);
     return p.accumulate ? launch(igemm2_dma1p_kernel<true>) : launch(igemm2_dma1p_kernel<false>);

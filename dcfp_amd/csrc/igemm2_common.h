@@ -24,6 +24,8 @@ struct Igemm2Params {
     int in_pitch;       // row pitch (floats) of the B source; > Wi: rows carry a zero tail of in_pitch - Wi floats, so a
                         // shifted 16-byte quad may hang over either row end and still read zeros (no border handling)
     int zfold;          // strided dgrad of a 1x1 conv: only phase `zfold - 1` has a tap; its tiles also write the zeros
+    const float* fan_src;   // igemm2_dma1p_kernel, gradient fan-in of a residual block: out = result + fan_src where the bit of
+    const unsigned long long* fan_mask;   // fan_mask is set (layout of dcfp_bn_apply_relu_mask_f32), fan_src laid out as out
     long long wp_nstride;   // igemm2_dma1p_kernel: floats between the weight copies of consecutive images (0: shared) - the
                             // batched GEMM of conv_winograd.hip, where "image" xi has its own transformed filter
     int tapskip;        // 9-tap LDS-DMA kernels: K-steps of kernel rows that lie wholly in the padding for a tile are skipped

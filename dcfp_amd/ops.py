@@ -392,6 +392,32 @@ def conv2d_dgrad(dy, w, xshape, stride, pad, dil, out=None, accumulate=False):
     return dx
 
 
+MASKED_FANIN = os.environ.get("DCFP_MASKED_FANIN", "1") not in ("0",)   # =0: the residual gradient is written and re-read (A/B)
+
+
+def conv2d_dgrad_fanin_ok(dyshape, w, xshape):
+    """True where conv2d_dgrad_fanin is available for this 1x1 stride-1 conv."""
+    d = _desc(xshape, w.shape, 1, 0, 1)
+    return MASKED_FANIN and bool(_lib.lib().dcfp_conv2d_dgrad_fanin_supported(C.byref(d)))
+
+
+def conv2d_dgrad_fanin(dy, w, xshape, fan_src, fan_mask):
+    """dx = dgrad(dy, w) + fan_src * mask (1-bit ReLU mask of bn_apply_relu_mask): the gradient fan-in of a residual
+    block without the residual branch's gradient ever being written."""
+    _require(dy, "dy"); _require(fan_src, "fan_src")
+    w = w if w.is_contiguous() else w.contiguous()
+    d = _desc(xshape, w.shape, 1, 0, 1)
+    dy, ns = _batch_strided(dy)
+    if tuple(fan_src.shape) != tuple(xshape) or not fan_src.is_contiguous():
+        raise RuntimeError("conv2d_dgrad_fanin: fan_src must be a contiguous tensor of the input shape")
+    dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+    ws, valid = _conv_workspace(w, _lib.CONV_DGRAD, d)
+    _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
+        _lib.lib().dcfp_conv2d_dgrad_fanin_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), _p(fan_src), _p(fan_mask),
+                                                    _p(ws), ws.numel(), valid, _stream()), "conv2d_dgrad_fanin"))
+    return dx
+
+
 def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=None, xform=None):
     """(dw, db); dw / db: optional destinations (the gradient arena's views).  xform: the transformed input the
     forward call left behind (conv2d_fwd(..., keep=)), taken instead of x where the library says so."""
@@ -900,8 +926,13 @@ class BottleneckFn(torch.autograd.Function):
         def wg(dy, inp, w, st=1, pd=0, dl=1, keep=None):
             return lambda: wgrad_into_param(dy, inp, w, None, st, pd, dl, keep=keep)[0]
 
-        # bn3 (+residual, ReLU): gradient of conv3's output and of the residual branch
-        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], True)
+        # bn3 (+residual, ReLU): gradient of conv3's output and of the residual branch.  Identity-shortcut blocks whose
+        # forward kept the ReLU mask as bits do not materialise the residual gradient dout * mask: conv1's dgrad adds
+        # it from (dout, mask) in its epilogue (conv2d_dgrad_fanin) - 4 B/element less written per block
+        mask3 = st3[4] if len(st3) > 4 else None
+        fanin = (not ctx.has_ds and mask3 is not None and ctx.needs_input_grad[0] and dout.is_contiguous()
+                 and tuple(dout.shape) == tuple(x.shape) and conv2d_dgrad_fanin_ok(None, w1, tuple(x.shape)))
+        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], not fanin)
         d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
         # conv3's weight gradient does not feed bn2: it runs between bn2's reduction and its dx
         dc2_out = pitched_buffer(tuple(c2.shape), ctx.pitch, "d_c2", c2.device) if ctx.pitch else None
@@ -922,7 +953,9 @@ class BottleneckFn(torch.autograd.Function):
             dw1, _ = wgrad_into_param(d_c1, x, w1, None, 1, 0, 1)
             dx = d_res
         grads[0] = dw1
-        if ctx.needs_input_grad[0]:
+        if fanin:
+            dx = conv2d_dgrad_fanin(d_c1, w1, tuple(x.shape), dout, mask3)
+        elif ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(d_c1, w1, tuple(x.shape), 1, 0, 1, out=dx, accumulate=True)
         else:
             dx = None

@@ -122,6 +122,15 @@ int dcfp_conv2d_wgrad_kept_f32_nchw(const DcfpConvDesc* d, const float* dy, int6
                                     size_t xform_bytes, float* dw, void* workspace, size_t workspace_bytes,
                                     dcfp_stream_t stream);
 
+/* Gradient fan-in of a residual block (networks/backbone/resnet.py:52-56, backward): dx = dgrad(dy) + fan_src * mask,
+ * mask = the 1-bit ReLU mask written by dcfp_bn_apply_relu_mask_f32, fan_src = the gradient that arrived at the block's
+ * output (layout of dx).  The residual branch's gradient dy * mask is then never materialised (the BatchNorm backward
+ * is called without its residual output).  Same workspace / wp_valid contract as dcfp_conv2d_dgrad_f32_nchw. */
+int dcfp_conv2d_dgrad_fanin_supported(const DcfpConvDesc* d);
+int dcfp_conv2d_dgrad_fanin_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride, const float* w, float* dx,
+                                     const float* fan_src, const void* fan_mask, void* workspace, size_t workspace_bytes,
+                                     int wp_valid, dcfp_stream_t stream);
+
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
  * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the
  * string rocprofv3 shows (demangled) for the launch; used by bench.py to label rooflines.

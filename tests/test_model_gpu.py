@@ -349,3 +349,50 @@ def test_eval_after_training_step_refolds_bn(cuda):
     scale = b1.abs().max().item()
     assert (a1 - b1).abs().max().item() <= 1e-4 * scale
     assert (a1 - a0).abs().max().item() > 1e-2 * scale      # the step really moved the output
+
+
+def _fanin_child():
+    """One training step of DeepLabv3-R50 at 2x3x512x1024 (the smallest size at which the identity-shortcut blocks of
+    layer1 / layer3 / layer4 reach the persistent 1x1 kernel): digests of the loss and of every parameter gradient."""
+    import hashlib
+    import json
+    dev = torch.device("cuda:0")
+    m = build("deeplabv3", "resnet50", True, dev)
+    m.conv_deepsup[3].p = 0.0
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 512, 1024, generator=g).to(dev)
+    lab = torch.randint(0, 19, (2, 512, 1024), generator=g).to(dev)
+    loss = m(x, lab, deepsup=True)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for _, p in m.named_parameters():
+        h.update(p.grad.detach().cpu().numpy().tobytes())
+    from dcfp_amd import ops
+    d = ops._desc((2, 1024, 64, 128), (256, 1024, 1, 1), 1, 0, 1)
+    print("FANIN_RESULT " + json.dumps({"loss": float(loss), "grads": h.hexdigest(),
+                                        "layer3_ok": bool(ops.conv2d_dgrad_fanin_ok(None, torch.empty(256, 1024, 1, 1), (2, 1024, 64, 128)))}))
+
+
+def test_masked_fanin_bit_identical_to_materialised_residual_gradient(cuda):
+    """ops.conv2d_dgrad_fanin (conv1's dgrad adds dout * ReLU-mask from the bit mask in its epilogue) against the path
+    that writes the residual gradient in the BatchNorm backward and accumulates onto it (DCFP_MASKED_FANIN=0): the same
+    sums in the same order - every parameter gradient of a full step must be the same bits."""
+    import json
+    import subprocess
+    import sys
+    res = []
+    for v in ("0", "1"):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, DCFP_MASKED_FANIN=v, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fanin-child"], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("FANIN_RESULT ")][-1][len("FANIN_RESULT "):]))
+    assert res[1]["layer3_ok"] and not res[0]["layer3_ok"]       # the switch switches
+    assert res[0]["loss"] == res[1]["loss"] and res[0]["grads"] == res[1]["grads"], res
+
+
+if __name__ == "__main__" and "--fanin-child" in __import__("sys").argv:
+    __import__("sys").path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _fanin_child()
