@@ -11,10 +11,12 @@
  *     allocates nothing and keeps no state between calls; all launches are
  *     stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default).
  *     The only process-wide state is a set of tuning switches read ONCE from the
- *     environment into function-local statics on first use (DCFP_CONV_MATH,
- *     DCFP_IGEMM_DMA, DCFP_IGEMM_DMA9, DCFP_IGEMM_2D, DCFP_IGEMM_BK32, DCFP_WGRAD_DMA, ...:
- *     kernel-selection A/B knobs, results are identical up to the documented fp32
- *     tolerances); changing them after the first call has no effect.
+ *     environment into function-local statics on first use: DCFP_CONV_MATH (bf16x3 opt-in),
+ *     DCFP_CONV_WINOGRAD (0 direct kernels only / 1 cost model, default / 2 wherever eligible),
+ *     DCFP_IGEMM_{DMA,DMA9,DMA8,2D,BK32,PERSIST,P128,TAPSKIP}, DCFP_WGRAD_{DMA,DMA_MIXED,WIDE,LOPSIDED,T192},
+ *     DCFP_WINO_VEC - kernel / algorithm selection A/B knobs, results are identical up to the documented
+ *     fp32 tolerances; changing them after the first call has no effect.  (A thread_local 16-entry cache
+ *     of dispatch decisions for dilated convs is the only other state.)
  *   - tensors are fp32, NCHW, dense unless a *_nstride (batch stride, in elements)
  *     argument says otherwise.
  *   - return value: 0 ok; <0 bad descriptor / unsupported shape (DCFP_E_*);
