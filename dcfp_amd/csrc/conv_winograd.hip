@@ -30,6 +30,12 @@ bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int
                           int Wo, bool pitched);
 bool dcfp_igemm2_persist();
 int dcfp_igemm2_ck_pad();
+// conv_winograd2.hip: the fused kernel (transforms inside the GEMM)
+bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_nstride, int pitch);
+size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
+int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
+                        float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out);
 
 namespace {
 
@@ -472,6 +478,10 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
         return DCFP_E_WORKSPACE;
+    if (!stat_part && !scale && dcfp_wino_fused_ok(N, H, W, d, M, Ck, in_nstride, in_pitch) &&
+        workspace_bytes >= dcfp_wino_fused_workspace_bytes(N, H, W, d, M, Ck))
+        return dcfp_wino_fused_run(in, in_nstride, in_pitch, w, sAm, sAc, flip, out, out_nstride, N, M, Ck, H, W, d,
+                                   accumulate, workspace, workspace_bytes, stream, xform_out);
     float* U = static_cast<float*>(workspace);
     float* V = xform_out ? xform_out : U + pl.u_floats;
     float* Mb = U + pl.u_floats + pl.v_floats;

@@ -1,0 +1,566 @@
+// conv_winograd2.hip — FUSED Winograd F(2x2, 3x3): input transform, the sixteen component GEMMs and the output
+// transform in ONE kernel (forward and dgrad of the wide 3x3 stride-1 convs: networks/backbone/resnet.py:27-28,
+// networks/tools/aspp.py:37-39, networks/deeplabv3.py:25-41).
+//
+// conv_winograd.hip runs the same algebra as three memory-bound passes around a batched GEMM and moves 9.3x the
+// algorithmic bytes (the 16-plane V written + read, the 16-plane M written + read).  Here a workgroup owns ALL 16
+// components xi of a (64 output channels x 64 tiles) block: 16 x 64 x 64 / 256 lanes = 256 accumulator registers per
+// lane (one wave per SIMD, like the 256 x 256 tile of the direct kernels), so
+//   * the output transform  y = A^T m A  is register arithmetic in the epilogue (each lane holds all 16 components of
+//     its 16 (channel, tile) elements) and only y is written - M never exists;
+//   * the B operand V = B^T d B is built on the fly: per K-step (8 input channels) every thread loads the 4x4 patches
+//     of TWO neighbouring tiles of ONE channel straight from x (16-byte / 8-byte buffer loads; out-of-image rows and
+//     columns read zeros through an out-of-range offset or the zero tail of a row-pitched x), transforms them
+//     (64 additions) and writes 16 x 8 bytes into the LDS image the MFMA fragments are read from - V never exists either
+//     (it is written on the side, each block 1/mblocks of the channels, when the weight gradient wants to take it over:
+//     dcfp_conv2d_fwd_keep_f32_nchw);
+//   * the A operand (the transformed filters U, <= 34 MB, L2-resident) is copied global -> LDS by LDS-DMA from a layout
+//     that is already MFMA-fragment order: Ug[c/8][m/64][xi][m%64/32][lane][kk] = U[xi][c = 8 cb + 2 kk + lane/32][m],
+//     so a lane's four K-pairs of one component are ONE ds_read_b128.
+// Operand traffic into LDS is 16 flop/B for A + B from V (tools/micro/wino_fused_probe.hip: 87 TF at C = 256, copies
+// alone 11 TB/s = the L2 -> LDS ceiling) - which is why B is transformed in the kernel instead of copied: the A copies
+// alone are free (133 TF with and without them).
+//
+// Tile numbering, super-blocks for dilation d, and the transforms' arithmetic (operation order included) are those of
+// conv_winograd.hip: V written on the side is bit-identical to wino_input_kernel's.
+#include "igemm2_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((vector_size(16)));
+typedef unsigned u32x2 __attribute__((vector_size(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ u32x4 make_desc(const void* base, unsigned bytes) {   // raw buffer: stride 0, 32-bit data
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 d = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return d;
+}
+
+constexpr int FBK = 8;                     // input channels per K-step
+constexpr int FSTAGE = 16 * FBK * 64;      // floats of one operand of one LDS stage (32 KB)
+
+struct WinoFusedParams {
+    const float* in;        // x (forward) or dy (dgrad): [N][Ck][H][pitch], images in_nstride floats apart
+    const float* in_base;   // descriptor base: `in` minus `lead` floats (readable zeros in front of a pitched tensor)
+    unsigned in_bytes;      // descriptor bound
+    int lead;
+    long long in_nstride;
+    int pitch;
+    const float* ug;        // transformed filters, fragment order (see above)
+    float* out;             // y (forward) or dx (dgrad): [N][M][H][W] dense rows, images out_nstride floats apart
+    long long out_nstride;
+    float* xform_out;       // nullable: V[16][Ck][T16]
+    float* stat_part;       // nullable: BatchNorm partials of y, [slot][M][2] = (mean, M2) over 128 outputs
+    int N, M, Ck, H, W, d, TH, TW;
+    long long T, T16;
+    int mblocks, tblocks, nk;
+    int accumulate;
+    int ragged_c;           // Ck % 8 != 0
+};
+
+// ---- patch loads.  A thread owns the tile pair (tp, tp + 1) of one channel; R[r][col] are the columns its two patches
+// touch in patch row r.  Column of patch A / B for patch column s:
+//   DM 1 (d = 1, pitched):  R[r][0..5] = 6 consecutive floats, A: s, B: s + 2          loads: x4 + x2 per row
+//   DM 2 (d = 2, pitched):  R[r][0..7] = 8 consecutive floats, A: 2s, B: 2s + 1        loads: x4 + x4 per row
+//   DM 4 (d >= 4 even, W even): R[r][2s..2s+1] = 2 floats at column w0 + s d            loads: 4 x x2 per row
+//   DM 0 (anything):        as DM 4 with 4-byte loads and per-element validity          loads: 8 x x1 per row
+template <int DM> struct PatchCfg;
+template <> struct PatchCfg<1> { static constexpr int NV = 8, NCOL = 6; };
+template <> struct PatchCfg<2> { static constexpr int NV = 8, NCOL = 8; };
+template <> struct PatchCfg<4> { static constexpr int NV = 16, NCOL = 8; };
+template <> struct PatchCfg<0> { static constexpr int NV = 32, NCOL = 8; };
+template <int DM> __device__ __forceinline__ constexpr int colA(int s) { return DM == 1 ? s : 2 * s; }
+template <int DM> __device__ __forceinline__ constexpr int colB(int s) { return DM == 1 ? s + 2 : 2 * s + 1; }
+
+template <int DM>
+__device__ __forceinline__ void load_patches(const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&voff)[PatchCfg<DM>::NV],
+                                             unsigned soff, float (&R)[4][8]) {
+    static_for<0, 4>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        if constexpr (DM == 1) {
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2 * r], soff, 0));
+            const f32x2 b = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[2 * r + 1], soff, 0));
+            R[r][0] = a[0]; R[r][1] = a[1]; R[r][2] = a[2]; R[r][3] = a[3]; R[r][4] = b[0]; R[r][5] = b[1];
+        } else if constexpr (DM == 2) {
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2 * r], soff, 0));
+            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2 * r + 1], soff, 0));
+            R[r][0] = a[0]; R[r][1] = a[1]; R[r][2] = a[2]; R[r][3] = a[3];
+            R[r][4] = b[0]; R[r][5] = b[1]; R[r][6] = b[2]; R[r][7] = b[3];
+        } else if constexpr (DM == 4) {
+            static_for<0, 4>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                const f32x2 a = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[4 * r + s], soff, 0));
+                R[r][2 * s] = a[0]; R[r][2 * s + 1] = a[1];
+            });
+        } else {
+            static_for<0, 8>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                R[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[8 * r + c], soff, 0));
+            });
+        }
+    });
+}
+
+// load I of the NV loads of a step (the K loop spreads them over its MFMA groups)
+template <int DM, int I>
+__device__ __forceinline__ void load_one(const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&voff)[PatchCfg<DM>::NV],
+                                         unsigned soff, float (&R)[4][8]) {
+    if constexpr (DM == 1) {
+        constexpr int r = I >> 1;
+        if constexpr ((I & 1) == 0) {
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[I], soff, 0));
+            R[r][0] = a[0]; R[r][1] = a[1]; R[r][2] = a[2]; R[r][3] = a[3];
+        } else {
+            const f32x2 b = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[I], soff, 0));
+            R[r][4] = b[0]; R[r][5] = b[1];
+        }
+    } else if constexpr (DM == 2) {
+        constexpr int r = I >> 1, c0 = 4 * (I & 1);
+        const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[I], soff, 0));
+        R[r][c0] = a[0]; R[r][c0 + 1] = a[1]; R[r][c0 + 2] = a[2]; R[r][c0 + 3] = a[3];
+    } else if constexpr (DM == 4) {
+        constexpr int r = I >> 2, s = I & 3;
+        const f32x2 a = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[I], soff, 0));
+        R[r][2 * s] = a[0]; R[r][2 * s + 1] = a[1];
+    } else {
+        constexpr int r = I >> 3, c = I & 7;
+        R[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[I], soff, 0));
+    }
+}
+
+// B^T p over the patch rows (the same expressions as wino_input_kernel)
+template <int DM>
+__device__ __forceinline__ void row_transform(const float (&R)[4][8], float (&q)[4][8]) {
+#pragma unroll
+    for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) {
+        q[0][c] = R[0][c] - R[2][c];
+        q[1][c] = R[1][c] + R[2][c];
+        q[2][c] = R[2][c] - R[1][c];
+        q[3][c] = R[1][c] - R[3][c];
+    }
+}
+template <int DM, int ROW>
+__device__ __forceinline__ void row_transform_one(const float (&R)[4][8], float (&q)[4][8]) {
+#pragma unroll
+    for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) {
+        if constexpr (ROW == 0) q[0][c] = R[0][c] - R[2][c];
+        if constexpr (ROW == 1) q[1][c] = R[1][c] + R[2][c];
+        if constexpr (ROW == 2) q[2][c] = R[2][c] - R[1][c];
+        if constexpr (ROW == 3) q[3][c] = R[1][c] - R[3][c];
+    }
+}
+// component xi = 4 r + s of patch A and patch B
+template <int DM, int XI>
+__device__ __forceinline__ f32x2 col_transform(const float (&q)[4][8]) {
+    constexpr int r = XI >> 2, s = XI & 3;
+    f32x2 o;
+    if constexpr (s == 0) { o[0] = q[r][colA<DM>(0)] - q[r][colA<DM>(2)]; o[1] = q[r][colB<DM>(0)] - q[r][colB<DM>(2)]; }
+    if constexpr (s == 1) { o[0] = q[r][colA<DM>(1)] + q[r][colA<DM>(2)]; o[1] = q[r][colB<DM>(1)] + q[r][colB<DM>(2)]; }
+    if constexpr (s == 2) { o[0] = q[r][colA<DM>(2)] - q[r][colA<DM>(1)]; o[1] = q[r][colB<DM>(2)] - q[r][colB<DM>(1)]; }
+    if constexpr (s == 3) { o[0] = q[r][colA<DM>(1)] - q[r][colA<DM>(3)]; o[1] = q[r][colB<DM>(1)] - q[r][colB<DM>(3)]; }
+    return o;
+}
+
+// SIDE: V is written on the side (p.xform_out).  RAGGED: Ck % 8 != 0, the channels past Ck in the last K-step read zeros.
+// The K loop is ONE basic block (no branch around the MFMAs: with the accumulators live across a diamond hipcc 7.2 moves
+// all 256 of them through VGPRs / scratch every iteration): conditional work is expressed through buffer offsets - an
+// out-of-range offset makes a load return zeros and drops a store.
+template <int DM, bool SIDE, bool RAGGED>
+__global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParams p) {
+    constexpr int NV = PatchCfg<DM>::NV;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][A 8192 | B 8192]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    // blocks b, b + 8, ... share an XCD (round-robin placement): the mblocks blocks of one tile block sit next to each
+    // other there, so the patches they all read are served by that XCD's L2
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int mb = jb % p.mblocks, tb = (jb / p.mblocks) * 8 + xcd;
+    if (tb >= p.tblocks) return;                                   // block-uniform
+    const long long t0 = (long long)tb * 64;
+    const int nk = p.nk, d = p.d, H = p.H, W = p.W, TW = p.TW, tpi = p.TH * p.TW, pitch = p.pitch;
+
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    const u32x4 a_desc = make_desc(p.ug, 0x7ffffffcu);
+    const unsigned lane16 = lane * 16u;
+
+    // ---- producer role: tile pair (tp, tp + 1), channel 2 wid + lhi of the K-step
+    const int ch = 2 * wid + lhi;
+    const long long tp = t0 + 2 * l31;
+    unsigned voff[NV];
+    {
+        const bool tvalid = tp < p.T;
+        const long long tq = tvalid ? tp : 0;
+        const int n = (int)(tq / tpi), tt = (int)(tq - (long long)n * tpi);
+        const int trow = tt / TW, tcol = tt - trow * TW;
+        const int h0 = trow + d * (trow / d) - d, w0 = tcol + d * (tcol / d) - d;
+        const int w0b = (tcol + 1) + d * ((tcol + 1) / d) - d;     // second tile of the pair (DM 0: any d)
+        const long long base = (long long)n * p.in_nstride + (long long)lhi * H * pitch + p.lead;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = h0 + r * d;
+            const bool rok = tvalid && (unsigned)h < (unsigned)H;
+            const long long row = base + (long long)h * pitch;
+            if constexpr (DM == 1 || DM == 2) {
+                // a vector that starts inside the row may hang over its end (and the first one over its start): the
+                // pitched layout keeps >= 4 zeros there
+                voff[2 * r] = (rok && w0 < W) ? (unsigned)((row + w0) * 4) : kOob;
+                voff[2 * r + 1] = (rok && w0 + 4 < W) ? (unsigned)((row + w0 + 4) * 4) : kOob;
+            } else if constexpr (DM == 4) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ww = w0 + s * d;                  // even, W even: the pair is inside or outside as a whole
+                    voff[4 * r + s] = (rok && (unsigned)ww < (unsigned)W) ? (unsigned)((row + ww) * 4) : kOob;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int ww = ((c & 1) ? w0b : w0) + (c >> 1) * d;
+                    voff[8 * r + c] = (rok && (unsigned)ww < (unsigned)W) ? (unsigned)((row + ww) * 4) : kOob;
+                }
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_base), 0,
+                                                                             p.in_bytes, 0x00020000);
+    const unsigned chan_bytes = (unsigned)(H * pitch) * 4u;
+    float R[4][8], q[4][8];
+    auto load_step = [&](int kt) {          // patches of K-step kt -> R
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(kt * FBK + 2 * wid_s) * chan_bytes);
+        if constexpr (RAGGED) {
+            unsigned vm[NV];
+            const bool cok = kt * FBK + ch < p.Ck;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vm[i] = cok ? voff[i] : kOob;
+            load_patches<DM>(in_rsrc, vm, soff, R);
+        } else {
+            load_patches<DM>(in_rsrc, voff, soff, R);
+        }
+    };
+    auto issue_a = [&](int kt, int buf) {   // the 32 KB A image of K-step kt: 8 of its 32 one-KB pieces per wave
+        const unsigned abase = (unsigned)((kt * p.mblocks + mb) * FSTAGE) * 4u;
+        static_for<0, 8>([&](auto q_) {
+            constexpr int qq = decltype(q_)::value;
+            const unsigned piece = (unsigned)(wid_s * 8 + qq);
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * 2 * FSTAGE) * 4u + piece * 1024u);
+            const unsigned a_s = __builtin_amdgcn_readfirstlane(abase + piece * 1024u);
+            const unsigned av = lane16;
+            const u32x4 ad = a_desc;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+        });
+    };
+    auto retire = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // component XI of the K-step whose row transform sits in q: into the B image of stage `buf` (and V on the side)
+    // V[xi][c][tp .. tp + 1]: one descriptor per component (a plane is Ck * T16 * 4 bytes < 2 GB), lane offset of the
+    // pair and the odd channel, the K-step's channel offset in the scalar offset
+    const long long vplane = (long long)p.Ck * p.T16;
+    const unsigned vs_lane = (SIDE && tp < p.T16) ? (unsigned)(((long long)lhi * p.T16 + tp) * 4) : kOob;
+    auto side_off = [&](int kt) -> unsigned {      // this block stores the K-steps kt % mblocks == mb
+        bool on = kt % p.mblocks == mb;
+        if constexpr (RAGGED) on = on && kt * FBK + ch < p.Ck;
+        return on ? vs_lane : kOob;
+    };
+    auto produce = [&](auto xi_, int kt, int buf, unsigned vs) {
+        constexpr int XI = decltype(xi_)::value;
+        const f32x2 o = col_transform<DM, XI>(q);
+        float* bs = smem + buf * 2 * FSTAGE + FSTAGE + (XI * FBK + ch) * 64 + 2 * l31;
+        *reinterpret_cast<f32x2*>(bs) = o;
+        if constexpr (SIDE) {
+            const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xform_out + XI * vplane, 0,
+                                                                                    (unsigned)(vplane * 4), 0x00020000);
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((long long)(kt * FBK + 2 * wid_s) * p.T16 * 4));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), v_rsrc, vs, soff, 0);
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // ---- prologue: stage 0 = K-step 0
+    load_step(0);
+    row_transform<DM>(R, q);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_a(0, 0);
+    {
+        const unsigned vs = side_off(0);
+        static_for<0, 16>([&](auto xi_) { produce(xi_, 0, 0, vs); });
+    }
+    load_step(nk > 1 ? 1 : 0);
+    retire();
+
+    const int a_lane = wm * 256 + lane * 4;
+    const int b_lane = lhi * 64 + wn * 32 + l31;
+    // ---- K loop.  A K-step is 16 slots, one per component g: slot g reads the fragments of component g (consumed one
+    // slot later) and issues the 4 MFMAs of component g - 1; slot 0 issues those of the PREVIOUS step's component 15, whose
+    // fragments stay in registers across the barrier - the matrix pipe has work queued while the waves meet and while the
+    // first fragments of the new stage arrive.  Beside the MFMAs a slot carries its share of building K-step kt + 1:
+    // slots 0..3 one row of B^T d each, every slot the component's column transform + LDS write (+ the V store), slots
+    // 0..7 one of the wave's 8 LDS-DMA pieces of A, slots 4..11 the patch loads of K-step kt + 2 (R is dead after slot 3).
+    f32x4 af[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float bf[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto step = [&](auto prod_, int kt, int cur) {
+        constexpr bool PROD = decltype(prod_)::value;
+        unsigned vs = kOob;
+        if constexpr (PROD) vs = side_off(kt + 1);
+        const float* As = smem + cur * 2 * FSTAGE + a_lane;
+        const float* Bs = smem + cur * 2 * FSTAGE + FSTAGE + b_lane;
+        const int ktl = kt + 2 < nk ? kt + 2 : nk - 1;     // (the last load is a harmless repeat: no branch in the loop)
+        const unsigned l_soff = __builtin_amdgcn_readfirstlane((unsigned)(ktl * FBK + 2 * wid_s) * chan_bytes);
+        unsigned vm[NV];
+        if constexpr (PROD) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vm[i] = voff[i];
+            if constexpr (RAGGED) {
+                const bool cok = ktl * FBK + ch < p.Ck;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) vm[i] = cok ? voff[i] : kOob;
+            }
+        }
+        const unsigned abase = (unsigned)(((kt + 1) * p.mblocks + mb) * FSTAGE) * 4u;
+        static_for<0, 16>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            constexpr int fb = g & 1, pg = (g + 15) & 15;
+            af[fb] = *reinterpret_cast<const f32x4*>(As + g * 512);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) bf[fb][kk] = Bs[(g * FBK + 2 * kk) * 64];
+            if constexpr (PROD && g < 4) row_transform_one<DM, g>(R, q);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][0], bf[fb ^ 1][0], acc[pg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROD) {
+                if constexpr (g < 8) {        // piece g of this wave's 8 LDS-DMA pieces of the next A image
+                    const unsigned piece = (unsigned)(wid_s * 8 + g);
+                    const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((cur ^ 1) * 2 * FSTAGE) * 4u + piece * 1024u);
+                    const unsigned a_s = __builtin_amdgcn_readfirstlane(abase + piece * 1024u);
+                    const unsigned av = lane16;
+                    const u32x4 ad = a_desc;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                 :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+                }
+            }
+            acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][1], bf[fb ^ 1][1], acc[pg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROD) produce(g_, kt + 1, cur ^ 1, vs);
+            acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][2], bf[fb ^ 1][2], acc[pg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROD && g >= 4 && g < 12) {
+                constexpr int per = NV / 8;
+                static_for<0, per>([&](auto j_) { load_one<DM, (g - 4) * per + decltype(j_)::value>(in_rsrc, vm, l_soff, R); });
+            }
+            acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][3], bf[fb ^ 1][3], acc[pg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        step(std::true_type{}, kt, cur);
+        retire();
+        cur ^= 1;
+    }
+    step(std::false_type{}, nk - 1, cur);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)        // component 15 of the last step
+        acc[15] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][kk], bf[1][kk], acc[15], 0, 0, 0);
+
+    // ---- epilogue: y = A^T m A per (channel, tile), this lane's tile and 16 channels
+    const long long te = t0 + wn * 32 + l31;
+    const bool tv = te < p.T;
+    const long long tq = tv ? te : 0;
+    const int n = (int)(tq / tpi), tt = (int)(tq - (long long)n * tpi);
+    const int trow = tt / TW, tcol = tt - trow * TW;
+    const int ho = trow + d * (trow / d), wo = tcol + d * (tcol / d);
+    const bool okr0 = tv && ho < H, okr1 = tv && ho + d < H;
+    const bool okc0 = wo < W, okc1 = wo + d < W;
+    const long long HW = (long long)H * W;
+    float* obase = p.out + (long long)n * p.out_nstride + (long long)ho * W + wo;
+    const int m_base = mb * 64 + wm * 32 + 4 * lhi;
+    const long long dW = (long long)d * W;
+    const int acc_out = p.accumulate;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m_base + (r & 3) + 8 * (r >> 2);
+        float u[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u[0][s] = (acc[0 + s][r] + acc[4 + s][r]) + acc[8 + s][r];
+            u[1][s] = (acc[4 + s][r] - acc[8 + s][r]) - acc[12 + s][r];
+        }
+        float o[2][2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            o[rr][0] = (u[rr][0] + u[rr][1]) + u[rr][2];
+            o[rr][1] = (u[rr][1] - u[rr][2]) - u[rr][3];
+        }
+        if (m < p.M) {
+            float* e = obase + (long long)m * HW;
+            if (acc_out) {
+                if (okr0 && okc0) e[0] += o[0][0];
+                if (okr0 && okc1) e[d] += o[0][1];
+                if (okr1 && okc0) e[dW] += o[1][0];
+                if (okr1 && okc1) e[dW + d] += o[1][1];
+            } else {
+                if (okr0 && okc0) e[0] = o[0][0];
+                if (okr0 && okc1) e[d] = o[0][1];
+                if (okr1 && okc0) e[dW] = o[1][0];
+                if (okr1 && okc1) e[dW + d] = o[1][1];
+            }
+        }
+    }
+}
+
+// Ug[cb][mb][xi][wm][lane][kk] = (G g G^T)[xi] of g = w[m * sAm + c * sAc + tap] (flip: 8 - tap), c = 8 cb + 2 kk + lane / 32,
+// m = 64 mb + 32 wm + lane % 32; zeros past M / Ck
+__global__ void __launch_bounds__(256) wino_filter2_kernel(const float* __restrict__ w, int sAm, int sAc, int flip, int M,
+                                                           int Ck, int CkP, int Mpad, float* __restrict__ Ug) {
+    const long long total = (long long)CkP * Mpad;
+    const int mblocks = Mpad / 64;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx / Mpad), m = (int)(idx - (long long)c * Mpad);
+        float g[9];
+        if (m < M && c < Ck) {
+            const float* src = w + (long long)m * sAm + (long long)c * sAc;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g[t] = src[flip ? 8 - t : t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g[t] = 0.f;
+        }
+        float r[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
+            r[0][k] = g0;
+            r[1][k] = 0.5f * ((g0 + g2) + g1);
+            r[2][k] = 0.5f * ((g0 + g2) - g1);
+            r[3][k] = g2;
+        }
+        const int cb = c >> 3, cl = c & 7, mb = m >> 6, ml = m & 63;
+        float* dst = Ug + ((((long long)(cb * mblocks + mb) * 16) * 2 + (ml >> 5)) * 64 + (cl & 1) * 32 + (ml & 31)) * 4 + (cl >> 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = r[i][0], b = r[i][1], cc = r[i][2];
+            dst[(4 * i + 0) * 512] = a;
+            dst[(4 * i + 1) * 512] = 0.5f * ((a + cc) + b);
+            dst[(4 * i + 2) * 512] = 0.5f * ((a + cc) - b);
+            dst[(4 * i + 3) * 512] = cc;
+        }
+    }
+}
+
+struct FusedPlan {
+    int TH, TW, mblocks, tblocks, nk, CkP, Mpad;
+    long long T, T16, ug_floats;
+};
+FusedPlan fused_plan(int N, int H, int W, int d, int M, int Ck) {
+    FusedPlan pl;
+    pl.TH = d * ((H + 2 * d - 1) / (2 * d));
+    pl.TW = d * ((W + 2 * d - 1) / (2 * d));
+    pl.TW = (pl.TW + 3) / 4 * 4;
+    pl.T = (long long)N * pl.TH * pl.TW;
+    pl.T16 = (pl.T + 15) / 16 * 16;
+    pl.CkP = (Ck + 7) / 8 * 8;
+    pl.Mpad = (M + 63) / 64 * 64;
+    pl.mblocks = pl.Mpad / 64;
+    pl.tblocks = (int)((pl.T + 63) / 64);
+    pl.nk = pl.CkP / 8;
+    pl.ug_floats = ((long long)16 * pl.CkP * pl.Mpad + 63) / 64 * 64;
+    return pl;
+}
+
+}  // namespace
+
+// DCFP_WINO_FUSED: 0 off (the three-pass path of conv_winograd.hip), 1 on (default)
+bool dcfp_wino_fused_enabled() {
+    static const int v = [] { const char* e = getenv("DCFP_WINO_FUSED"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+// patch-load mode for this input, or -1 where the kernel does not apply
+static int fused_mode(int N, int H, int W, int d, int Ck, long long in_nstride, int pitch) {
+    if (pitch <= 0) pitch = W;
+    const long long span = (long long)(N - 1) * in_nstride + (long long)((Ck + 7) / 8 * 8) * H * pitch + 64;
+    if (span * 4 >= 0x7fffff00LL) return -1;                 // 32-bit byte offsets with bit 31 as the out-of-range mark
+    if (d == 1 && pitch >= W + 4) return 1;
+    if (d == 2 && pitch >= W + 4) return 2;
+    if (d >= 4 && d % 2 == 0 && W % 2 == 0 && pitch % 2 == 0 && in_nstride % 2 == 0) return 4;
+    return 0;
+}
+
+bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_nstride, int pitch) {
+    if (!dcfp_wino_fused_enabled()) return false;
+    if (M < 64 || Ck < 64) return false;
+    const FusedPlan pl = fused_plan(N, H, W, d, M, Ck);
+    if (pl.T16 >= (1LL << 30) || (long long)pl.tblocks * pl.mblocks + 8 * pl.mblocks >= (1LL << 31)) return false;
+    if ((long long)pl.CkP * pl.Mpad * 16 * 4 >= 0x7fffff00LL) return false;
+    return fused_mode(N, H, W, d, Ck, in_nstride, pitch) >= 0;
+}
+
+size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck) {
+    return (size_t)fused_plan(N, H, W, d, M, Ck).ug_floats * sizeof(float);
+}
+
+int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
+                        float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out) {
+    const FusedPlan pl = fused_plan(N, H, W, d, M, Ck);
+    if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < (size_t)pl.ug_floats * sizeof(float))
+        return DCFP_E_WORKSPACE;
+    const int pitch = in_pitch > 0 ? in_pitch : W;
+    const int mode = fused_mode(N, H, W, d, Ck, in_nstride, pitch);
+    if (mode < 0) return DCFP_E_UNSUPPORTED;
+    float* Ug = static_cast<float*>(workspace);
+    {
+        long long b = ((long long)pl.CkP * pl.Mpad + 255) / 256;
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL(wino_filter2_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, sAm, sAc, flip, M, Ck, pl.CkP,
+                           pl.Mpad, Ug);
+    }
+    WinoFusedParams p;
+    p.in = in;
+    p.lead = (mode == 1 || mode == 2) ? 4 : 0;          // the pitched layout keeps pitch - W >= 4 readable zeros in front
+    p.in_base = in - p.lead;
+    p.in_bytes = (unsigned)(((long long)(N - 1) * in_nstride + (long long)Ck * H * pitch + p.lead) * 4);
+    p.in_nstride = in_nstride;
+    p.pitch = pitch;
+    p.ug = Ug;
+    p.out = out;
+    p.out_nstride = out_nstride;
+    p.xform_out = xform_out;
+    p.stat_part = nullptr;
+    p.N = N; p.M = M; p.Ck = Ck; p.H = H; p.W = W; p.d = d; p.TH = pl.TH; p.TW = pl.TW;
+    p.T = pl.T; p.T16 = pl.T16;
+    p.mblocks = pl.mblocks; p.tblocks = pl.tblocks; p.nk = pl.nk;
+    p.accumulate = accumulate;
+    p.ragged_c = (Ck % 8) != 0;
+    const long long grid = (long long)((pl.tblocks + 7) / 8) * 8 * pl.mblocks;
+    const size_t lds = (size_t)4 * FSTAGE * sizeof(float);
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+        DCFP_RETURN_LAUNCH();
+    };
+    if (xform_out && (long long)Ck * pl.T16 * 4 >= 0x7fffff00LL) return DCFP_E_UNSUPPORTED;
+    const bool ragged = (Ck % 8) != 0;
+#define DCFP_WF(DM_) (xform_out ? (ragged ? launch(wino_fused_kernel<DM_, true, true>) : launch(wino_fused_kernel<DM_, true, false>)) \
+                                : (ragged ? launch(wino_fused_kernel<DM_, false, true>) : launch(wino_fused_kernel<DM_, false, false>)))
+    switch (mode) {
+        case 1: return DCFP_WF(1);
+        case 2: return DCFP_WF(2);
+        case 4: return DCFP_WF(4);
+        default: return DCFP_WF(0);
+    }
+#undef DCFP_WF
+}
