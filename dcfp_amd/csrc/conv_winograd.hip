@@ -35,7 +35,7 @@ bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_
 size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                         float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out);
+                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part);
 
 namespace {
 
@@ -478,10 +478,19 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
         return DCFP_E_WORKSPACE;
-    if (!stat_part && !scale && dcfp_wino_fused_ok(N, H, W, d, M, Ck, in_nstride, in_pitch) &&
-        workspace_bytes >= dcfp_wino_fused_workspace_bytes(N, H, W, d, M, Ck))
+    // The fused kernel (conv_winograd2.hip) where it measures faster than the three passes (same-box A/B,
+    // profiles/r03_wino_fused_ab.txt): everywhere except (a) a forward that must leave V behind for the weight gradient
+    // with more than 256 input channels - the three-pass path has V anyway, the fused kernel writes it on the side at
+    // HBM speed (1...5 GB) - and (b) an accumulating dgrad with >= 1024 output channels (short K, the read-modify-write
+    // of the output dominates).  DCFP_WINO_FUSED=2 takes it wherever it applies (tests).
+    static const int fused_mode = [] { const char* e = getenv("DCFP_WINO_FUSED"); return e ? atoi(e) : 1; }();
+    const bool fused_wins = fused_mode == 2 || (!(xform_out && Ck > 256) && !(accumulate && M >= 1024));
+    if (!scale && fused_wins && dcfp_wino_fused_ok(N, H, W, d, M, Ck, in_nstride, in_pitch) &&
+        workspace_bytes >= dcfp_wino_fused_workspace_bytes(N, H, W, d, M, Ck)) {
+        if (stat_part && (!dcfp_wino_stat_slots(N, H, W, d) || accumulate)) return DCFP_E_UNSUPPORTED;
         return dcfp_wino_fused_run(in, in_nstride, in_pitch, w, sAm, sAc, flip, out, out_nstride, N, M, Ck, H, W, d,
-                                   accumulate, workspace, workspace_bytes, stream, xform_out);
+                                   accumulate, workspace, workspace_bytes, stream, xform_out, stat_part);
+    }
     float* U = static_cast<float*>(workspace);
     float* V = xform_out ? xform_out : U + pl.u_floats;
     float* Mb = U + pl.u_floats + pl.v_floats;

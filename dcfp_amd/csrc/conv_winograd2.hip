@@ -58,7 +58,9 @@ struct WinoFusedParams {
     long long T, T16;
     int mblocks, tblocks, nk;
     int accumulate;
-    int ragged_c;           // Ck % 8 != 0
+    int ragged_c;           // Ck % 16 != 0
+    int vec_epi;            // 16-byte output stores (W % 4 == 0, 16-byte aligned images, 32-bit byte offsets)
+    unsigned out_bytes;
 };
 
 // ---- patch loads.  A thread owns the tile pair (tp, tp + 1) of one channel; R[r][col] are the columns its two patches
@@ -66,12 +68,11 @@ struct WinoFusedParams {
 //   DM 1 (d = 1, pitched):  R[r][0..5] = 6 consecutive floats, A: s, B: s + 2          loads: x4 + x2 per row
 //   DM 2 (d = 2, pitched):  R[r][0..7] = 8 consecutive floats, A: 2s, B: 2s + 1        loads: x4 + x4 per row
 //   DM 4 (d >= 4 even, W even): R[r][2s..2s+1] = 2 floats at column w0 + s d            loads: 4 x x2 per row
-//   DM 0 (anything):        as DM 4 with 4-byte loads and per-element validity          loads: 8 x x1 per row
+// (anything else - a dense x with dilation 1 / 2, odd dilations - stays on the three-pass path of conv_winograd.hip)
 template <int DM> struct PatchCfg;
 template <> struct PatchCfg<1> { static constexpr int NV = 8, NCOL = 6; };
 template <> struct PatchCfg<2> { static constexpr int NV = 8, NCOL = 8; };
 template <> struct PatchCfg<4> { static constexpr int NV = 16, NCOL = 8; };
-template <> struct PatchCfg<0> { static constexpr int NV = 32, NCOL = 8; };
 template <int DM> __device__ __forceinline__ constexpr int colA(int s) { return DM == 1 ? s : 2 * s; }
 template <int DM> __device__ __forceinline__ constexpr int colB(int s) { return DM == 1 ? s + 2 : 2 * s + 1; }
 
@@ -89,16 +90,11 @@ __device__ __forceinline__ void load_patches(const __amdgpu_buffer_rsrc_t rsrc, 
             const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[2 * r + 1], soff, 0));
             R[r][0] = a[0]; R[r][1] = a[1]; R[r][2] = a[2]; R[r][3] = a[3];
             R[r][4] = b[0]; R[r][5] = b[1]; R[r][6] = b[2]; R[r][7] = b[3];
-        } else if constexpr (DM == 4) {
+        } else {
             static_for<0, 4>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
                 const f32x2 a = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[4 * r + s], soff, 0));
                 R[r][2 * s] = a[0]; R[r][2 * s + 1] = a[1];
-            });
-        } else {
-            static_for<0, 8>([&](auto c_) {
-                constexpr int c = decltype(c_)::value;
-                R[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[8 * r + c], soff, 0));
             });
         }
     });
@@ -121,13 +117,10 @@ __device__ __forceinline__ void load_one(const __amdgpu_buffer_rsrc_t rsrc, cons
         constexpr int r = I >> 1, c0 = 4 * (I & 1);
         const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[I], soff, 0));
         R[r][c0] = a[0]; R[r][c0 + 1] = a[1]; R[r][c0 + 2] = a[2]; R[r][c0 + 3] = a[3];
-    } else if constexpr (DM == 4) {
+    } else {
         constexpr int r = I >> 2, s = I & 3;
         const f32x2 a = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[I], soff, 0));
         R[r][2 * s] = a[0]; R[r][2 * s + 1] = a[1];
-    } else {
-        constexpr int r = I >> 3, c = I & 7;
-        R[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[I], soff, 0));
     }
 }
 
@@ -164,7 +157,7 @@ __device__ __forceinline__ f32x2 col_transform(const float (&q)[4][8]) {
     return o;
 }
 
-// SIDE: V is written on the side (p.xform_out).  RAGGED: Ck % 8 != 0, the channels past Ck in the last K-step read zeros.
+// SIDE: V is written on the side (p.xform_out).  RAGGED: Ck % 16 != 0, the channels past Ck in the last K-steps read zeros.
 // The K loop is ONE basic block (no branch around the MFMAs: with the accumulators live across a diamond hipcc 7.2 moves
 // all 256 of them through VGPRs / scratch every iteration): conditional work is expressed through buffer offsets - an
 // out-of-range offset makes a load return zeros and drops a store.
@@ -197,7 +190,6 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
         const int n = (int)(tq / tpi), tt = (int)(tq - (long long)n * tpi);
         const int trow = tt / TW, tcol = tt - trow * TW;
         const int h0 = trow + d * (trow / d) - d, w0 = tcol + d * (tcol / d) - d;
-        const int w0b = (tcol + 1) + d * ((tcol + 1) / d) - d;     // second tile of the pair (DM 0: any d)
         const long long base = (long long)n * p.in_nstride + (long long)lhi * H * pitch + p.lead;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -209,17 +201,11 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
                 // pitched layout keeps >= 4 zeros there
                 voff[2 * r] = (rok && w0 < W) ? (unsigned)((row + w0) * 4) : kOob;
                 voff[2 * r + 1] = (rok && w0 + 4 < W) ? (unsigned)((row + w0 + 4) * 4) : kOob;
-            } else if constexpr (DM == 4) {
+            } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int ww = w0 + s * d;                  // even, W even: the pair is inside or outside as a whole
                     voff[4 * r + s] = (rok && (unsigned)ww < (unsigned)W) ? (unsigned)((row + ww) * 4) : kOob;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int ww = ((c & 1) ? w0b : w0) + (c >> 1) * d;
-                    voff[8 * r + c] = (rok && (unsigned)ww < (unsigned)W) ? (unsigned)((row + ww) * 4) : kOob;
                 }
             }
         }
@@ -227,17 +213,19 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_base), 0,
                                                                              p.in_bytes, 0x00020000);
     const unsigned chan_bytes = (unsigned)(H * pitch) * 4u;
-    float R[4][8], q[4][8];
-    auto load_step = [&](int kt) {          // patches of K-step kt -> R
+    // patches of K-step j live in R[j & 1]: loaded during step j - 3 (slots 8..15), consumed during step j - 1 (slots 0..3)
+    float R[2][4][8], q[4][8];
+    auto load_step = [&](int kt, auto b_) {          // patches of K-step kt -> R[b]
+        constexpr int b = decltype(b_)::value;
         const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(kt * FBK + 2 * wid_s) * chan_bytes);
         if constexpr (RAGGED) {
             unsigned vm[NV];
             const bool cok = kt * FBK + ch < p.Ck;
 #pragma unroll
             for (int i = 0; i < NV; ++i) vm[i] = cok ? voff[i] : kOob;
-            load_patches<DM>(in_rsrc, vm, soff, R);
+            load_patches<DM>(in_rsrc, vm, soff, R[b]);
         } else {
-            load_patches<DM>(in_rsrc, voff, soff, R);
+            load_patches<DM>(in_rsrc, voff, soff, R[b]);
         }
     };
     auto issue_a = [&](int kt, int buf) {   // the 32 KB A image of K-step kt: 8 of its 32 one-KB pieces per wave
@@ -257,27 +245,44 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
+    // end of a K-step of the loop: everything but the NV youngest vector-memory operations has landed - those are the patch
+    // loads issued in slots 8..15 (behind the last LDS-DMA piece), which have another whole step to arrive
+    // (SIDE: a step that stores V issues its 16 stores in slots 8..15 too, behind the last LDS-DMA piece: 16 more
+    //  operations may stay in flight.  The branches around the stores and between the two waits are scalar and hold no MFMA.)
+    auto retire_keep_loads = [&](bool stored) {
+        if (SIDE && stored) {
+            if constexpr (NV == 8) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+        } else {
+            if constexpr (NV == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
     // component XI of the K-step whose row transform sits in q: into the B image of stage `buf` (and V on the side)
     // V[xi][c][tp .. tp + 1]: one descriptor per component (a plane is Ck * T16 * 4 bytes < 2 GB), lane offset of the
     // pair and the odd channel, the K-step's channel offset in the scalar offset
     const long long vplane = (long long)p.Ck * p.T16;
     const unsigned vs_lane = (SIDE && tp < p.T16) ? (unsigned)(((long long)lhi * p.T16 + tp) * 4) : kOob;
-    auto side_off = [&](int kt) -> unsigned {      // this block stores the K-steps kt % mblocks == mb
-        bool on = kt % p.mblocks == mb;
-        if constexpr (RAGGED) on = on && kt * FBK + ch < p.Ck;
+    auto side_on = [&](int kt) -> bool { return SIDE && kt % p.mblocks == mb; };   // this block stores these K-steps
+    auto side_off = [&](int kt) -> unsigned {
+        bool on = true;
+        if constexpr (RAGGED) on = kt * FBK + ch < p.Ck;
         return on ? vs_lane : kOob;
     };
-    auto produce = [&](auto xi_, int kt, int buf, unsigned vs) {
+    auto side_store = [&](auto xi_, f32x2 o, int kt, unsigned vs) {
+        constexpr int XI = decltype(xi_)::value;
+        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xform_out + XI * vplane, 0,
+                                                                                (unsigned)(vplane * 4), 0x00020000);
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((long long)(kt * FBK + 2 * wid_s) * p.T16 * 4));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), v_rsrc, vs, soff, 0);
+    };
+    auto produce = [&](auto xi_, int buf) -> f32x2 {
         constexpr int XI = decltype(xi_)::value;
         const f32x2 o = col_transform<DM, XI>(q);
         float* bs = smem + buf * 2 * FSTAGE + FSTAGE + (XI * FBK + ch) * 64 + 2 * l31;
         *reinterpret_cast<f32x2*>(bs) = o;
-        if constexpr (SIDE) {
-            const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xform_out + XI * vplane, 0,
-                                                                                    (unsigned)(vplane * 4), 0x00020000);
-            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((long long)(kt * FBK + 2 * wid_s) * p.T16 * 4));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), v_rsrc, vs, soff, 0);
-        }
+        return o;
     };
 
     f32x16 acc[16];
@@ -287,15 +292,23 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     // ---- prologue: stage 0 = K-step 0
-    load_step(0);
-    row_transform<DM>(R, q);
+    load_step(0, std::integral_constant<int, 0>{});
+    row_transform<DM>(R[0], q);
     __builtin_amdgcn_sched_barrier(0);
     issue_a(0, 0);
     {
         const unsigned vs = side_off(0);
-        static_for<0, 16>([&](auto xi_) { produce(xi_, 0, 0, vs); });
+        const bool st = side_on(0);
+        static_for<0, 16>([&](auto xi_) {
+            const f32x2 o = produce(xi_, 0);
+            if constexpr (SIDE) {
+                if (st) side_store(xi_, o, 0, vs);
+            }
+        });
     }
-    load_step(nk > 1 ? 1 : 0);
+    load_step(1, std::integral_constant<int, 1>{});            // nk >= 2, even
+    __builtin_amdgcn_sched_barrier(0);                         // (issue order = the loop's: set 1 wholly before set 0)
+    load_step(nk > 2 ? 2 : 1, std::integral_constant<int, 0>{});
     retire();
 
     const int a_lane = wm * 256 + lane * 4;
@@ -305,16 +318,20 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
     // fragments stay in registers across the barrier - the matrix pipe has work queued while the waves meet and while the
     // first fragments of the new stage arrive.  Beside the MFMAs a slot carries its share of building K-step kt + 1:
     // slots 0..3 one row of B^T d each, every slot the component's column transform + LDS write (+ the V store), slots
-    // 0..7 one of the wave's 8 LDS-DMA pieces of A, slots 4..11 the patch loads of K-step kt + 2 (R is dead after slot 3).
+    // 0..7 one of the wave's 8 LDS-DMA pieces of A, slots 8..15 the patch loads of K-step kt + 3 into the register set the
+    // row transform has just released (two sets: a load has more than a whole step to land).  The step parity is static
+    // (the loop body is two steps): LDS stage and register set are compile-time.
     f32x4 af[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float bf[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    auto step = [&](auto prod_, int kt, int cur) {
+    auto step = [&](auto prod_, auto par_, int kt) {
         constexpr bool PROD = decltype(prod_)::value;
+        constexpr int cur = decltype(par_)::value, rb = cur ^ 1;
         unsigned vs = kOob;
-        if constexpr (PROD) vs = side_off(kt + 1);
+        bool st = false;
+        if constexpr (PROD) { vs = side_off(kt + 1); st = side_on(kt + 1); }
         const float* As = smem + cur * 2 * FSTAGE + a_lane;
         const float* Bs = smem + cur * 2 * FSTAGE + FSTAGE + b_lane;
-        const int ktl = kt + 2 < nk ? kt + 2 : nk - 1;     // (the last load is a harmless repeat: no branch in the loop)
+        const int ktl = kt + 3 < nk ? kt + 3 : nk - 1;     // (the last loads are harmless repeats: no branch in the loop)
         const unsigned l_soff = __builtin_amdgcn_readfirstlane((unsigned)(ktl * FBK + 2 * wid_s) * chan_bytes);
         unsigned vm[NV];
         if constexpr (PROD) {
@@ -327,13 +344,20 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
             }
         }
         const unsigned abase = (unsigned)(((kt + 1) * p.mblocks + mb) * FSTAGE) * 4u;
+        f32x2 okeep[8];
         static_for<0, 16>([&](auto g_) {
             constexpr int g = decltype(g_)::value;
             constexpr int fb = g & 1, pg = (g + 15) & 15;
             af[fb] = *reinterpret_cast<const f32x4*>(As + g * 512);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) bf[fb][kk] = Bs[(g * FBK + 2 * kk) * 64];
-            if constexpr (PROD && g < 4) row_transform_one<DM, g>(R, q);
+            if constexpr (PROD && g < 4) {
+                row_transform_one<DM, g>(R[rb], q);
+                // pin the row here: left alone, hipcc sinks these subtractions to the column transforms of slots 4..15,
+                // which keeps R alive under the loads of slots 8..15 (register copies behind fresh loads = stalls)
+#pragma unroll
+                for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) asm volatile("" : "+v"(q[g][c]));
+            }
             __builtin_amdgcn_sched_barrier(0);
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][0], bf[fb ^ 1][0], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -350,25 +374,39 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
             }
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][1], bf[fb ^ 1][1], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROD) produce(g_, kt + 1, cur ^ 1, vs);
+            if constexpr (PROD) {
+                const f32x2 o = produce(g_, cur ^ 1);
+                if constexpr (SIDE) {
+                    if constexpr (g < 8) okeep[g] = o;
+                    else if (st) {
+                        side_store(std::integral_constant<int, g - 8>{}, okeep[g - 8], kt + 1, vs);
+                        side_store(g_, o, kt + 1, vs);
+                    }
+                }
+            }
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][2], bf[fb ^ 1][2], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROD && g >= 4 && g < 12) {
+            if constexpr (PROD && g >= 8) {
                 constexpr int per = NV / 8;
-                static_for<0, per>([&](auto j_) { load_one<DM, (g - 4) * per + decltype(j_)::value>(in_rsrc, vm, l_soff, R); });
+                static_for<0, per>([&](auto j_) { load_one<DM, (g - 8) * per + decltype(j_)::value>(in_rsrc, vm, l_soff, R[rb]); });
             }
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][3], bf[fb ^ 1][3], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
 
-    int cur = 0;
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        step(std::true_type{}, kt, cur);
-        retire();
-        cur ^= 1;
+    constexpr std::integral_constant<int, 0> even{};
+    constexpr std::integral_constant<int, 1> odd{};
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) {          // nk is even: the producing steps 0 .. nk - 2 are pairs + one
+        step(std::true_type{}, even, kt);
+        retire_keep_loads(side_on(kt + 1));
+        step(std::true_type{}, odd, kt + 1);
+        retire_keep_loads(side_on(kt + 2));
     }
-    step(std::false_type{}, nk - 1, cur);
+    step(std::true_type{}, even, nk - 2);
+    retire();
+    step(std::false_type{}, odd, nk - 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)        // component 15 of the last step
         acc[15] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][kk], bf[1][kk], acc[15], 0, 0, 0);
@@ -383,25 +421,101 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
     const bool okr0 = tv && ho < H, okr1 = tv && ho + d < H;
     const bool okc0 = wo < W, okc1 = wo + d < W;
     const long long HW = (long long)H * W;
-    float* obase = p.out + (long long)n * p.out_nstride + (long long)ho * W + wo;
-    const int m_base = mb * 64 + wm * 32 + 4 * lhi;
-    const long long dW = (long long)d * W;
+    const int m_lane = mb * 64 + wm * 32 + 4 * lhi;
     const int acc_out = p.accumulate;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m_base + (r & 3) + 8 * (r >> 2);
+    float* const sp0 = p.stat_part;          // BatchNorm partials: (mean, M2) over the 128 outputs of this wave's 32 tiles
+    const long long slot = (long long)tb * 2 + wn;
+    auto out_transform = [&](int r, float (&o)[2][2]) {
         float u[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u[0][s] = (acc[0 + s][r] + acc[4 + s][r]) + acc[8 + s][r];
             u[1][s] = (acc[4 + s][r] - acc[8 + s][r]) - acc[12 + s][r];
         }
-        float o[2][2];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             o[rr][0] = (u[rr][0] + u[rr][1]) + u[rr][2];
             o[rr][1] = (u[rr][1] - u[rr][2]) - u[rr][3];
         }
+    };
+    auto stats = [&](int m, const float (&o)[2][2]) {
+        // block-uniform; only launched where every tile lies wholly inside the image (dcfp_wino_stat_slots)
+        float sum = (o[0][0] + o[0][1]) + (o[1][0] + o[1][1]);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum * (1.0f / 128.0f);
+        const float d0 = o[0][0] - mean, d1 = o[0][1] - mean, d2 = o[1][0] - mean, d3 = o[1][1] - mean;
+        float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, 64);
+        if (l31 == 0 && m < p.M && t0 + wn * 32 < p.T) {      // (T is a multiple of 32 here, not necessarily of 64)
+            float* sp = sp0 + (slot * p.M + m) * 2;
+            sp[0] = mean; sp[1] = m2;
+        }
+    };
+    if (p.vec_epi) {
+        // 16-byte stores: the 2x2 outputs of neighbouring tiles are regrouped among the lanes of a quad so that every lane
+        // holds 4 consecutive pixels of one output row.  Offsets are 32-bit (checked by the host); a lane without
+        // anything to store carries an out-of-range offset (the store is dropped): no branches.
+        auto xor1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };
+        auto xor2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); };
+        const bool odd = l31 & 1, hi2 = l31 & 2;
+        int row, col;       // the row / first column this lane stores
+        bool ok;
+        if constexpr (DM == 4) {
+            const int i = l31 & 3;
+            row = ho + (i >> 1) * d;
+            col = wo - i + (i & 1) * d;
+            ok = tv && row < H && col < W;
+        } else if constexpr (DM == 2) {
+            row = ho + (odd ? d : 0);
+            col = wo - (odd ? 1 : 0);
+            ok = tv && row < H && col < W;
+        } else {
+            row = ho + (odd ? 1 : 0);
+            col = wo - (odd ? 2 : 0);
+            ok = tv && row < H && col < W;
+        }
+        const unsigned evoff = ok ? (unsigned)(((long long)n * p.out_nstride + (long long)m_lane * HW + (long long)row * W + col) * 4) : kOob;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+        const unsigned HW4 = (unsigned)HW * 4u;
+        static_for<0, 16>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            constexpr int mr = (r & 3) + 8 * (r >> 2);
+            float o[2][2];
+            out_transform(r, o);
+            if (sp0) stats(m_lane + mr, o);
+            f32x4 v;
+            if constexpr (DM == 4) {
+                const float x0 = odd ? o[0][0] : o[0][1], x1 = odd ? o[1][0] : o[1][1];
+                const float y0 = xor1(x0), y1 = xor1(x1);
+                const float b0 = odd ? y0 : o[0][0], b1 = odd ? o[0][1] : y0, b2 = odd ? y1 : o[1][0], b3 = odd ? o[1][1] : y1;
+                const float z0 = hi2 ? b0 : b2, z1 = hi2 ? b1 : b3;
+                const float w0 = xor2(z0), w1 = xor2(z1);
+                v[0] = hi2 ? w0 : b0; v[1] = hi2 ? w1 : b1; v[2] = hi2 ? b2 : w0; v[3] = hi2 ? b3 : w1;
+            } else {
+                const float s0 = odd ? o[0][0] : o[1][0], s1 = odd ? o[0][1] : o[1][1];
+                const float r0 = xor1(s0), r1 = xor1(s1);
+                if constexpr (DM == 2) {
+                    v[0] = odd ? r0 : o[0][0]; v[1] = odd ? o[1][0] : r0; v[2] = odd ? r1 : o[0][1]; v[3] = odd ? o[1][1] : r1;
+                } else {
+                    v[0] = odd ? r0 : o[0][0]; v[1] = odd ? r1 : o[0][1]; v[2] = odd ? o[1][0] : r0; v[3] = odd ? o[1][1] : r1;
+                }
+            }
+            const unsigned vo = (m_lane + mr < p.M) ? evoff : kOob;
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)mr * HW4);
+            if (acc_out) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, vo, so, 0));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, vo, so, 0);
+        });
+        return;
+    }
+    float* obase = p.out + (long long)n * p.out_nstride + (long long)ho * W + wo;
+    const long long dW = (long long)d * W;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m_lane + (r & 3) + 8 * (r >> 2);
+        float o[2][2];
+        out_transform(r, o);
         if (m < p.M) {
             float* e = obase + (long long)m * HW;
             if (acc_out) {
@@ -416,6 +530,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
                 if (okr1 && okc1) e[dW + d] = o[1][1];
             }
         }
+        if (sp0) stats(m, o);
     }
 }
 
@@ -469,7 +584,7 @@ FusedPlan fused_plan(int N, int H, int W, int d, int M, int Ck) {
     pl.TW = (pl.TW + 3) / 4 * 4;
     pl.T = (long long)N * pl.TH * pl.TW;
     pl.T16 = (pl.T + 15) / 16 * 16;
-    pl.CkP = (Ck + 7) / 8 * 8;
+    pl.CkP = (Ck + 15) / 16 * 16;                 // an even number of K-steps (the K loop's body is two steps)
     pl.Mpad = (M + 63) / 64 * 64;
     pl.mblocks = pl.Mpad / 64;
     pl.tblocks = (int)((pl.T + 63) / 64);
@@ -489,12 +604,12 @@ bool dcfp_wino_fused_enabled() {
 // patch-load mode for this input, or -1 where the kernel does not apply
 static int fused_mode(int N, int H, int W, int d, int Ck, long long in_nstride, int pitch) {
     if (pitch <= 0) pitch = W;
-    const long long span = (long long)(N - 1) * in_nstride + (long long)((Ck + 7) / 8 * 8) * H * pitch + 64;
+    const long long span = (long long)(N - 1) * in_nstride + (long long)((Ck + 15) / 16 * 16) * H * pitch + 64;
     if (span * 4 >= 0x7fffff00LL) return -1;                 // 32-bit byte offsets with bit 31 as the out-of-range mark
     if (d == 1 && pitch >= W + 4) return 1;
     if (d == 2 && pitch >= W + 4) return 2;
-    if (d >= 4 && d % 2 == 0 && W % 2 == 0 && pitch % 2 == 0 && in_nstride % 2 == 0) return 4;
-    return 0;
+    if (d >= 4 && d % 2 == 0 && W % 2 == 0) return 4;
+    return -1;
 }
 
 bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_nstride, int pitch) {
@@ -512,7 +627,7 @@ size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck
 
 int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                         float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out) {
+                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part) {
     const FusedPlan pl = fused_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < (size_t)pl.ug_floats * sizeof(float))
         return DCFP_E_WORKSPACE;
@@ -537,12 +652,20 @@ int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, con
     p.out = out;
     p.out_nstride = out_nstride;
     p.xform_out = xform_out;
-    p.stat_part = nullptr;
+    p.stat_part = stat_part;
     p.N = N; p.M = M; p.Ck = Ck; p.H = H; p.W = W; p.d = d; p.TH = pl.TH; p.TW = pl.TW;
     p.T = pl.T; p.T16 = pl.T16;
     p.mblocks = pl.mblocks; p.tblocks = pl.tblocks; p.nk = pl.nk;
     p.accumulate = accumulate;
-    p.ragged_c = (Ck % 8) != 0;
+    p.ragged_c = (Ck % 16) != 0;
+    {
+        const long long ospan = ((long long)(N - 1) * out_nstride + (long long)M * H * W) * 4;
+        p.vec_epi = W % 4 == 0 && out_nstride % 4 == 0 && dcfp_aligned16(out) && ospan < 0x7fffff00LL &&
+                    (mode != 4 || d % 4 == 0);
+        p.out_bytes = p.vec_epi ? (unsigned)ospan : 0u;
+        static const int no_vec = [] { const char* e = getenv("DCFP_WF_SCALAR_EPI"); return e ? atoi(e) : 0; }();
+        if (no_vec) p.vec_epi = 0;
+    }
     const long long grid = (long long)((pl.tblocks + 7) / 8) * 8 * pl.mblocks;
     const size_t lds = (size_t)4 * FSTAGE * sizeof(float);
     auto launch = [&](auto kern) -> int {
@@ -553,14 +676,14 @@ int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, con
         DCFP_RETURN_LAUNCH();
     };
     if (xform_out && (long long)Ck * pl.T16 * 4 >= 0x7fffff00LL) return DCFP_E_UNSUPPORTED;
-    const bool ragged = (Ck % 8) != 0;
+    const bool ragged = (Ck % 16) != 0;
 #define DCFP_WF(DM_) (xform_out ? (ragged ? launch(wino_fused_kernel<DM_, true, true>) : launch(wino_fused_kernel<DM_, true, false>)) \
                                 : (ragged ? launch(wino_fused_kernel<DM_, false, true>) : launch(wino_fused_kernel<DM_, false, false>)))
     switch (mode) {
         case 1: return DCFP_WF(1);
         case 2: return DCFP_WF(2);
         case 4: return DCFP_WF(4);
-        default: return DCFP_WF(0);
+        default: return DCFP_E_UNSUPPORTED;
     }
 #undef DCFP_WF
 }
