@@ -86,7 +86,7 @@ def host_cores():
     return max(1, min(n, cap))
 
 
-def cpu_baseline(backbone, n, h, w, full_hw):
+def cpu_baseline(backbone, n, h, w, full_hw, reps=3):
     """The CPU oracle (a port of the reference's CPU path) on a bounded sample: the same model
     at batch `n` (ASPP image-pool BN needs >= 2) and h x w pixels; images/s are scaled by the
     pixel ratio to the full 1024x2048 workload."""
@@ -107,13 +107,18 @@ def cpu_baseline(backbone, n, h, w, full_hw):
     lab = torch.randint(0, 19, (n, h, w), generator=g)
     lab[torch.rand(n, h, w, generator=g) < 0.05] = 255
     mask = torch.ones(n, 512)
-    t0 = time.perf_counter()
-    tr.step(x, lab, dropout_mask=mask)
-    dt = time.perf_counter() - t0
+    times = []
+    for i in range(reps + 1):               # first step untimed: oneDNN primitive creation, allocator warm-up
+        t0 = time.perf_counter()
+        tr.step(x, lab, dropout_mask=mask)
+        if i:
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     scale = (h * w) / float(full_hw[0] * full_hw[1])
     return {"value": (n / dt) * scale, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 step of the CPU oracle (oracle/train_step.py), DeepLabv3-{backbone} batch {n} at "
-                      f"{h}x{w} ({dt:.1f} s), images/s scaled by the pixel ratio {scale:.4f} to 1024x2048"}
+            "sample": f"median of {reps} steps (after 1 warm-up step) of the CPU oracle (oracle/train_step.py), "
+                      f"DeepLabv3-{backbone} batch {n} at {h}x{w} ({dt:.1f} s per step), images/s scaled by the pixel "
+                      f"ratio {scale:.4f} to 1024x2048", "step_s": times}
 
 
 def roofline_from_profile(recs, images_per_step, step_s):
@@ -193,12 +198,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv, worker=None, device_count=None, poll_s=0.2):
+def _tail(path, n=30):
+    try:
+        with open(path, "r", errors="replace") as f:
+            return "".join(f.readlines()[-n:])
+    except OSError:
+        return ""
+
+
+def launch_ranks(n, argv, worker=None, device_count=None, poll_s=0.2, timeout_s=480.0):
     """`python bench.py --gpus N` without a launcher: start N CHILD worker processes, one per GPU
     (scripts/cs/pretrain.sh:31 + engine.py:38-46: one process per device, env:// rendezvous), wait
     for them and forward rank 0's JSON line.  Runs before anything in this process touches the GPU
     (torch.cuda.device_count() does not initialise it), never exec()s, and fails non-zero when
-    fewer than N devices are visible instead of silently measuring one."""
+    fewer than N devices are visible instead of silently measuring one.
+    The wait has a DEADLINE (`timeout_s`, --rank-timeout): a rank stuck in the RCCL rendezvous or in a collective must
+    not hang the caller.  On a failure or at the deadline exactly the children started here are stopped, and the
+    parent says which ranks were still alive and prints the tail of every rank's stderr (RCCL warnings included:
+    the children run with NCCL_DEBUG=WARN unless the caller set it)."""
     have = torch.cuda.device_count() if device_count is None else device_count
     if have < n:
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) visible; refusing to report a "
@@ -206,20 +223,25 @@ def launch_ranks(n, argv, worker=None, device_count=None, poll_s=0.2):
         return 2
     worker = worker or [sys.executable, os.path.abspath(__file__)]
     port = _free_port()
-    procs = []
+    import tempfile
+    import threading
+    logdir = tempfile.mkdtemp(prefix="dcfp_bench_ranks_")
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(worker + list(argv), env=env, text=True,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        env.setdefault("NCCL_DEBUG", "WARN")
+        errs.append(open(os.path.join(logdir, f"rank{r}.stderr"), "w"))
+        procs.append(subprocess.Popen(worker + list(argv), env=env, text=True, stderr=errs[r],
+                                      stdout=subprocess.PIPE if r == 0 else errs[r]))
     # drain rank 0's stdout on a thread so a chatty worker cannot fill the pipe
-    import threading
     lines = []
     t = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
     t.start()
     rc = 0
     pending = set(range(n))
+    deadline = time.monotonic() + timeout_s
     while pending and rc == 0:
         for r in list(pending):
             code = procs[r].poll()
@@ -228,8 +250,12 @@ def launch_ranks(n, argv, worker=None, device_count=None, poll_s=0.2):
                 if code != 0:
                     rc = code if code > 0 else 1
                     print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
+        if pending and rc == 0 and time.monotonic() > deadline:
+            rc = 124
+            print(f"bench.py: deadline of {timeout_s:.0f} s passed with rank(s) {sorted(pending)} of {n} still running "
+                  f"(rendezvous on 127.0.0.1:{port}); stopping them", file=sys.stderr)
         time.sleep(poll_s)
-    for r in pending:          # a rank failed: stop exactly the children started here
+    for r in pending:          # a rank failed or the deadline passed: stop exactly the children started here
         procs[r].terminate()
     for r in pending:
         try:
@@ -237,6 +263,12 @@ def launch_ranks(n, argv, worker=None, device_count=None, poll_s=0.2):
         except subprocess.TimeoutExpired:
             procs[r].kill()
     t.join(timeout=30)
+    for f in errs:
+        f.close()
+    for r in range(n):          # the workers' stderr: everything when all went well is just forwarded, tails on failure
+        text = _tail(os.path.join(logdir, f"rank{r}.stderr"), 40 if rc else 10 ** 6)
+        if text:
+            print(f"---- rank {r} stderr{' (tail)' if rc else ''} ----\n{text}", file=sys.stderr, end="")
     if rc:
         return rc
     recs = [l for l in lines if l.startswith("{")]
@@ -265,14 +297,18 @@ def main():
     ap.add_argument("--cpu-sample", default="2,512,1024", help="n,h,w of the CPU baseline sample")
     ap.add_argument("--channel-cfg", default=None,
                     help="time the slim model described by this channel_cfg.pth instead (not the headline config)")
-    ap.add_argument("--no-alt", action="store_true",
-                    help="skip the extra leg that re-times the step with DCFP_CONV_MATH=bf16x3")
+    ap.add_argument("--alt-legs", action="store_true",
+                    help="also re-time the step in child processes with DCFP_CONV_WINOGRAD=0 (direct kernels only) and "
+                         "with the opt-in DCFP_CONV_MATH=bf16x3 (off-contract: narrower multiplicands); off by default")
+    ap.add_argument("--no-alt", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rank-timeout", type=float, default=480.0,
+                    help="seconds the --gpus N parent waits for its ranks before it stops them and reports")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in SyncBN+DDP and run the collectives even at world size 1 (rehearsal)")
     args, _ = ap.parse_known_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent: no GPU call before this point
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.rank_timeout))   # parent: no GPU call before this point
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus is not None and args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} contradicts WORLD_SIZE={world} set by the launcher")
@@ -336,10 +372,15 @@ def main():
         step(it); it += 1
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for k in range(args.steps):
         last = step(it); it += 1
+        marks[k + 1].record()              # per-step device time (the headline is the wall clock around all K steps)
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,11 +389,26 @@ def main():
     value = global_batch * args.steps / dt
     step_s = dt / args.steps
 
-    roof, extra = None, None
+    roof, extra, comm = None, None, None
+    reducer = getattr(model, "reducer", None) if ddp else None
     if not args.no_roofline:
+        if reducer is not None:
+            reducer.timing = True
         ops.profile_start()
         step(it); it += 1
         recs = ops.profile_stop()
+        if reducer is not None:
+            reducer.timing = False
+            # data-parallel step: what the collectives cost where they are exposed.  The 115 forward SyncBN all-gathers sit
+            # on the compute stream (HIP-event time of each); the gradient all-reduces are overlapped with backward - what
+            # is left of them is the wait at the end of backward; `alone` = the same all-reduces with nothing to overlap.
+            sync = [ms for (kind, _, _, ms) in recs if kind == "syncbn_allgather"]
+            exposed = reducer.exposed_ms()
+            alone = reducer.alone_ms()
+            comm = {"syncbn_exposed_ms": sum(sync), "syncbn_allgathers": len(sync),
+                    "grad_allreduce_ms": alone, "grad_allreduce_exposed_ms": exposed,
+                    "allreduce_overlapped_frac": (1.0 - exposed / alone) if (alone and exposed is not None) else None}
+            recs = [r for r in recs if r[0] != "syncbn_allgather"]
         if rank == 0:
             roof, extra = roofline_from_profile(recs, args.batch, step_s)
     fence()
@@ -369,7 +425,7 @@ def main():
     # reads the switch once per process, so the leg runs in a child after this process let go of
     # its device memory.
     alt = direct = None
-    if (rank == 0 and world == 1 and not args.no_alt and not args.force_ddp and not args.channel_cfg
+    if (rank == 0 and world == 1 and args.alt_legs and not args.force_ddp and not args.channel_cfg
             and os.environ.get("DCFP_CONV_MATH", "") == "" and os.environ.get("DCFP_CONV_WINOGRAD", "") == ""):
         del model, seg_model, optimizer, train_pruning, images, labels
         import gc
@@ -377,7 +433,7 @@ def main():
         torch.cuda.empty_cache()
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup",
                str(args.warmup), "--backbone", args.backbone, "--batch", str(args.batch), "--size", args.size,
-               "--no-cpu-baseline", "--no-roofline", "--no-alt"]
+               "--no-cpu-baseline", "--no-roofline"]
 
         def leg(env_extra, what):
             try:
@@ -399,7 +455,7 @@ def main():
     if rank == 0:
         out = {"metric": "training images/sec at 1024x2048 DeepLabv3-R101", "value": value, "unit": "images/s",
                "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "median_ms_per_step": median_ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if os.environ.get("DCFP_CONV_MATH", "") in ("", "f32") else "f32 via bf16x3 split",
                "data": "synthetic",
@@ -414,7 +470,7 @@ def main():
                           "global_batch": global_batch, "parallelism": f"dp{world}"},
                "final_loss": last, "peak_mem_GiB": peak_mem,
                "grad_allreduce_launches_per_step": getattr(getattr(model, "reducer", None), "launched", None) if ddp else None,
-               "sgd_table_rebuilds": sgd_rebuilds,
+               "sgd_table_rebuilds": sgd_rebuilds, "comm": comm,
                "conv_roofline_images_per_s_per_gpu_at_100pct": 11.97 if (H, W, args.backbone, args.channel_cfg) == (1024, 2048, "resnet101", None) else None,
                "roofline": roof, "cpu_baseline": cpu, "direct_conv": direct, "alt_math": alt, "detail": extra}
         json_out.write(json.dumps(out) + "\n")

@@ -78,21 +78,38 @@ class ParamArena:
     # ------------------------------------------------------------------ lookup / validity
     @staticmethod
     def of(params):
-        """The arena that already holds exactly these parameters (still valid), or a new one."""
+        """The arena that already holds exactly these parameters - in ANY order: the optimizer walks them by param
+        group (decay / no-decay, optimizer.py:18-33), the data-parallel wrapper in module order - and is still valid;
+        otherwise a new one.  An arena that carries a gradient reducer is never replaced silently: its parameters
+        would lose the exchange (ranks stepping on local gradients without an error)."""
         params = [p for p in dict.fromkeys(params)]
         slot = getattr(params[0], "_dcfp_slot", None) if params else None
         if slot is not None and slot.arena.covers(params):
             return slot.arena
+        for p in params:
+            old = getattr(p, "_dcfp_slot", None)
+            if old is not None and old.arena.reducer is not None and old.arena.live(old.index):
+                raise RuntimeError(
+                    "ParamArena.of: these parameters belong to an arena with a gradient reducer (data-parallel "
+                    "wrapper) but are not exactly its parameter set; build the optimizer over the same trainable "
+                    "parameters as Engine.data_parallel, or wrap the model after changing them")
         return ParamArena(params)
 
     def covers(self, params):
+        """True when `params` is exactly this arena's parameter set (order-independent) and every one of them still
+        lives in it (not after model.to(...) / a load by assignment)."""
         if len(params) != len(self.params):
             return False
         base = self.flat_param.data_ptr()
-        for p, q, o in zip(params, self.params, self.offsets):
-            if p is not q or p.data_ptr() != base + 4 * o:     # e.g. after model.to(...) / load by assignment
+        seen = 0
+        for p in params:
+            slot = getattr(p, "_dcfp_slot", None)
+            if slot is None or slot.arena is not self or self.params[slot.index] is not p:
                 return False
-        return True
+            if p.data_ptr() != base + 4 * self.offsets[slot.index]:
+                return False
+            seen += 1
+        return seen == len(self.params) and len(set(map(id, params))) == seen
 
     def live(self, index):
         p = self.params[index]
@@ -144,6 +161,8 @@ class ParamArena:
         if token == 1:
             param.grad = view
         else:
+            if self.reducer is not None:
+                self.reducer.check_not_in_flight(idx)
             if add is not None:
                 add(view, out)
             else:
@@ -200,7 +219,26 @@ class GradReducer:
         self.use_avg = backend == "nccl"
         self._active = False
         self.launched = 0                # all-reduces issued in the last backward (bench / tests)
+        self.timing = False              # bench.py: record how long finalize() keeps the compute stream waiting
         arena.reducer = self
+
+    def begin_step(self):
+        """Start of a training step (DataParallel.forward): drop whatever a backward that raised left behind, and make
+        a step that never reaches the exchange visible (`launched` stays 0)."""
+        if self._active:
+            for w, _ in getattr(self, "works", []):
+                w.wait()
+        self._active = False
+        self.works = []
+        self.launched = 0
+
+    def check_not_in_flight(self, index):
+        """A second gradient for a parameter whose range is already being all-reduced (a parameter used twice in one
+        graph) would race with the collective and miss the average."""
+        if self._active and self.pending[self.chunk_of[index]] == -1:
+            raise RuntimeError("GradReducer: a second gradient arrived for a parameter whose range is already being "
+                               "exchanged (parameter used twice in one backward); use n_chunks=1 ranges cut after "
+                               "its last use, or torch_ddp=True")
 
     def _begin(self):
         self._active = True
@@ -244,12 +282,47 @@ class GradReducer:
                     if not self.ready[i]:
                         self.arena.grad_views[i].zero_()
                 self._launch(c)
+        timed = self.timing and torch.cuda.is_available() and self.arena.flat_grad.is_cuda
+        if timed:       # how long the compute stream really waits for the exchanges at the end of backward
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w, buf in self.works:
             w.wait()
             if not self.use_avg:
                 buf.div_(self.world)
+        if timed:
+            e1.record()
+            self.exposed_events = (e0, e1)
         self.works = []
         self._active = False
+
+    def exposed_ms(self):
+        """Compute-stream time spent waiting for the gradient exchanges at the end of the last backward run with
+        `timing` set (the part of the all-reduces that backward did not hide)."""
+        ev = getattr(self, "exposed_events", None)
+        if ev is None:
+            return None
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1])
+
+    def alone_ms(self, reps=3):
+        """The same all-reduces issued back to back with nothing to overlap (on a scratch copy of the ranges)."""
+        if not self.arena.flat_grad.is_cuda:
+            return None
+        scratch = torch.zeros_like(self.arena.flat_grad)
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        best = None
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for (_, _, f0, f1) in self.bounds:
+                dist.all_reduce(scratch[f0:f1], op=op, group=self.group)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1)
+            best = t if best is None else min(best, t)
+        return best
 
 
 def reduce_now(arena, group=None):

@@ -38,9 +38,21 @@ class DataParallel(torch.nn.Module):
                 for b in bufs:
                     b.copy_(flat[off:off + b.numel()].view(b.shape))
                     off += b.numel()
+        # the broadcasts wrote through the flat tensors: neither a Parameter's version counter nor ops.WEIGHT_EPOCH
+        # moved, so permuted-weight copies / folded-BN caches of a forward that ran before wrapping would be stale
+        from . import ops
+        ops.WEIGHT_EPOCH[0] += 1
         self.reducer = GradReducer(self.arena, group, n_chunks)
+        self._params = params
 
     def forward(self, *args, **kwargs):
+        if torch.is_grad_enabled():
+            for p in self._params:          # e.g. an optimizer built over another parameter list re-homed them
+                slot = getattr(p, "_dcfp_slot", None)
+                if slot is None or slot.arena is not self.arena:
+                    raise RuntimeError("DataParallel: a parameter left the gradient arena of this wrapper - its "
+                                       "gradient would not be exchanged between the ranks")
+            self.reducer.begin_step()
         return self.module(*args, **kwargs)
 
 
@@ -92,6 +104,10 @@ class Engine(object):
         if self.distributed:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
             if torch_ddp:
+                from . import arena
+                if arena.DIRECT:
+                    raise RuntimeError("Engine.data_parallel(torch_ddp=True) needs DCFP_ARENA_DIRECT=0: with direct "
+                                       "arena writes the gradients bypass torch DDP's hooks")
                 ids = [self.local_rank] if torch.cuda.is_available() else None
                 return torch.nn.parallel.DistributedDataParallel(
                     model, device_ids=ids, output_device=self.local_rank if ids else None,

@@ -124,24 +124,42 @@ def pitched_buffer(shape, pitch, key, device):
     return buf
 
 
+class PitchLease:
+    """Held by the autograd node that reads a module's persistent pitched buffer in its backward.  The buffer is busy
+    while a lease on it is alive: `release()` (end of that backward) or the death of the node - a grad-enabled forward
+    whose graph is dropped without backward, an exception between forward and backward - frees it for the next forward."""
+    __slots__ = ("slot", "__weakref__")
+
+    def __init__(self, slot):
+        self.slot = slot
+        slot["lease"] = weakref.ref(self)
+
+    def release(self):
+        if self.slot.get("lease") is not None and self.slot["lease"]() is self:
+            self.slot["lease"] = None
+
+
+def _pitch_busy(slot):
+    ref = slot.get("lease")
+    return ref is not None and ref() is not None
+
+
 def owner_pitched(owner, shape, pitch, device, track=True):
     """The persistent row-pitched buffer of a module's output (it lives from the forward to the backward of the
-    conv that reads it): (view, slot).  slot["busy"] is set while a graph holds the buffer - a second forward
-    before that graph's backward gets a fresh buffer instead (slot None)."""
+    conv that reads it): (view, lease).  While a graph holds a lease on the buffer, a second forward gets a fresh
+    buffer instead (lease None)."""
     slot = getattr(owner, "_dcfp_pitch", None) if owner is not None else None
-    if slot is not None and not slot["busy"] and tuple(slot["y"].shape) == tuple(shape) and _pitch_of(slot["y"]) == pitch \
-            and slot["y"].device == device:
+    if slot is not None and not _pitch_busy(slot) and tuple(slot["y"].shape) == tuple(shape) \
+            and _pitch_of(slot["y"]) == pitch and slot["y"].device == device:
         view = slot["y"]
     else:
         view = new_pitched(shape, pitch, device)
-        if owner is not None and (slot is None or not slot["busy"]):
-            slot = {"y": view, "busy": False}
+        if owner is not None and (slot is None or not _pitch_busy(slot)):
+            slot = {"y": view, "lease": None}
             owner._dcfp_pitch = slot
         else:
             slot = None
-    if slot is not None and track:
-        slot["busy"] = True
-    return view, (slot if track else None)
+    return view, (PitchLease(slot) if (slot is not None and track) else None)
 
 
 def new_pitched(shape, pitch, device):
@@ -656,7 +674,12 @@ def sync_bn_stats(mean, var, count, group, run=None, running=None):
     world = dist.get_world_size(group)
     local = torch.cat([mean, var, _count_tensor(count, mean.device)])
     allv = torch.empty(world, local.numel(), device=mean.device, dtype=mean.dtype)
-    dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group)
+    # (exposed on the compute stream: the normalisation that follows needs the pooled statistics; bench.py sums these)
+    if mean.is_cuda:
+        _timed("syncbn_allgather", None, 4.0 * local.numel() * world,
+               lambda: dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group))
+    else:
+        dist.all_gather_into_tensor(allv, local.unsqueeze(0), group=group)
     if mean.is_cuda:
         out = torch.empty(2 * Cc + 1, device=mean.device, dtype=torch.float32)
         check(_lib.lib().dcfp_syncbn_combine_f32(_p(allv), world, Cc, _p(out), _p(out[Cc:]), _p(out[2 * Cc:]),
@@ -795,9 +818,12 @@ class BatchNormActFn(torch.autograd.Function):
         x = x.contiguous()
         # pitch_cfg = (owner module, y_pitch, dx_pitch): write y row-pitched for the 3x3 conv that reads it next /
         # write dx row-pitched for the 3x3 conv that produced x (their shifted operands: conv_pitch)
-        out, ctx.pitch_slot, ctx.dx_pitch = None, None, 0
+        out, ctx.pitch_slot, ctx.dx_pitch, ctx.dx_key = None, None, 0, "bn_dx"
         if pitch_cfg is not None:
             owner, y_pitch, ctx.dx_pitch = pitch_cfg
+            # (the gradient handed to autograd is a view of a persistent buffer: one per owning module, so that a later
+            #  BatchNorm backward of the same shape cannot overwrite a gradient autograd still holds)
+            ctx.dx_key = ("bn_dx", id(owner))
             if y_pitch and residual is None:
                 out, ctx.pitch_slot = owner_pitched(owner, tuple(x.shape), y_pitch, x.device,
                                                     track=torch.is_grad_enabled())
@@ -819,11 +845,11 @@ class BatchNormActFn(torch.autograd.Function):
         relu, training, eps, count, group, has_res = ctx.cfg
         state = (mean, var, count_t if count_t is not None else count, group)
         need_res = has_res and ctx.needs_input_grad[5]
-        dx_out = pitched_buffer(tuple(x.shape), ctx.dx_pitch, "bn_dx", x.device) if ctx.dx_pitch else None
+        dx_out = pitched_buffer(tuple(x.shape), ctx.dx_pitch, ctx.dx_key, x.device) if ctx.dx_pitch else None
         dx, dgamma, dbeta, dres = bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, need_res,
                                                    dx_out=dx_out)
         if ctx.pitch_slot is not None:
-            ctx.pitch_slot["busy"] = False
+            ctx.pitch_slot.release()
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
@@ -960,7 +986,7 @@ class BottleneckFn(torch.autograd.Function):
         else:
             dx = None
         if ctx.pitch_slot is not None:
-            ctx.pitch_slot["busy"] = False      # y1's buffer may be reused by the next forward of this block
+            ctx.pitch_slot.release()            # y1's buffer may be reused by the next forward of this block
         return (dx, None) + tuple(grads)
 
 
@@ -1077,6 +1103,7 @@ class ForkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)      # an unused tap (deepsup=False) sends None, not a zero tensor + a full add
         return x.view_as(x), x.view_as(x)
 
     @staticmethod

@@ -303,6 +303,56 @@ def lr_schedule():
     np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), **rec)
 
 
+def _ref_function_source(lines, name):
+    """Source text of the top-level function `name` of a reference file that cannot be imported."""
+    start = next(i for i, l in enumerate(lines) if l.startswith(f"def {name}("))
+    end = next((i for i in range(start + 1, len(lines)) if lines[i].startswith("def ")), len(lines))
+    return "\n".join(lines[start:end])
+
+
+def eval_golden():
+    """evaluate.py imports cv2 / datasets and cannot be imported here; its prediction drivers and metrics are pure
+    torch / numpy functions, so their own source text is executed (pad, predict_sliding, predict_whole,
+    predict_multiscale, get_confusion_matrix: evaluate.py:113-117, 145-247; the mIoU lines of main(): 374-380).
+    Accommodation: Tensor.cuda is the identity while they run (predict_sliding moves every tile to the GPU)."""
+    from math import ceil
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import evalmetrics
+    lines = open(os.path.join(REF, "evaluate.py")).read().splitlines()
+    ns = {"np": np, "torch": torch, "F": F, "nn": nn, "ceil": ceil}
+    for fn in ("pad", "predict_sliding", "predict_whole", "predict_multiscale", "get_confusion_matrix"):
+        exec(_ref_function_source(lines, fn), ns)
+    a = next(i for i, l in enumerate(lines) if l.strip().startswith("pos = confusion_matrix.sum(1)"))
+    b = next(i for i in range(a, len(lines)) if lines[i].strip().startswith("mean_IU = IU_array.mean()"))
+    body = "\n".join("    " + l.strip() for l in lines[a:b + 1])
+    exec("def miou_lines(confusion_matrix):\n" + body + "\n    return p, r, IU_array, mean_IU\n", ns)
+    classes, tile = 4, (24, 36)
+    img = fill.closed_form_input(2, 56, 75)[:1]
+    net = evalmetrics.position_net(classes)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a_, **k_: self
+    try:
+        rec = {"sliding": ns["predict_sliding"](net, img, tile, classes).numpy(),
+               "sliding_small": ns["predict_sliding"](net, img[:, :, :20, :30], tile, classes).numpy()}   # image < tile
+        for whole in (False, True):
+            for align in (True, False):
+                rec[f"ms_whole{int(whole)}_align{int(align)}"] = ns["predict_multiscale"](
+                    net, img, tile, [0.75, 1.0, 1.25], classes, True, align, whole).numpy()
+        rec["ms_noflip"] = ns["predict_multiscale"](net, img, tile, [0.5, 1.0], classes, False, True, False).numpy()
+    finally:
+        torch.Tensor.cuda = real_cuda
+    g = np.random.RandomState(7)
+    gt = g.randint(0, 19, size=20000)
+    pred = np.where(g.rand(20000) < 0.7, gt, g.randint(0, 19, size=20000))
+    pred[gt == 18] = 3                                        # a class that is never recognised (IoU 0)
+    cm = ns["get_confusion_matrix"](gt, pred, 19)
+    p_, r_, iu, miou = ns["miou_lines"](cm)
+    rec.update(gt=gt.astype(np.int64), pred=pred.astype(np.int64), cm=cm, precision=np.float64(p_), recall=np.float64(r_),
+               iou=iu, miou=np.float64(miou), tile=np.array(tile), classes=np.int64(classes))
+    np.savez_compressed(os.path.join(OUT, "evalmetrics.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -327,3 +377,5 @@ if __name__ == "__main__":
         flops_golden()
     if "gsrl" in which:
         gsrl_golden()
+    if "eval" in which:          # added in round 3 (leaves the other fixtures untouched)
+        eval_golden()

@@ -10,6 +10,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if os.environ.get("STUB_FAIL_RANK") == str(rank):
     sys.exit(7)
 if os.environ.get("STUB_HANG_RANK") == str(rank):
+    print(f"stub rank {rank}: entering a collective that never completes", file=sys.stderr, flush=True)
     time.sleep(60)
 print("noise line from rank", rank)
 rec = {"n_gpus": world, "rccl_ranks": int(os.environ.get("STUB_RCCL_RANKS", world)), "rank": rank,

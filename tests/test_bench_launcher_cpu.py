@@ -50,6 +50,18 @@ def test_launcher_propagates_rank_failure_and_stops_the_others():
     assert time.time() - t0 < 45                    # the hanging rank 0 was terminated, not waited for
 
 
+def test_launcher_deadline_stops_a_stuck_rank_and_says_which():
+    # config 4 has never met RCCL at N > 1: a rank stuck in the rendezvous / a collective must end in a report, not a hang
+    call = ("import sys, bench; sys.exit(bench.launch_ranks(2, ['--gpus', '2'], worker={stub!r}, device_count=2, "
+            "timeout_s=3.0))").format(stub=STUB)
+    t0 = time.time()
+    r = _run(call, {"STUB_HANG_RANK": "1"})
+    assert r.returncode == 124 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    assert time.time() - t0 < 45
+    assert "deadline of 3 s passed with rank(s) [1] of 2 still running" in r.stderr
+    assert "---- rank 1 stderr (tail) ----" in r.stderr and "entering a collective that never completes" in r.stderr
+
+
 def test_launcher_rejects_a_wrong_world_size_report():
     r = _run(_CALL.format(n=2, stub=STUB, have=2), {"STUB_RCCL_RANKS": "1"})
     assert r.returncode != 0 and "rccl_ranks=1" in r.stderr

@@ -30,7 +30,9 @@ def _child():
         ignore_label = 255; num_classes = 19; class_weights = None
 
     class A:
-        no_decay = None; optim = "sgd"; momentum = 0.9; learning_rate = 1e-3; weight_decay = 5e-4
+        # two param groups (optimizer.py:18-33): the optimizer walks the parameters in decay / no-decay order, the
+        # data-parallel wrapper in module order - they must still share ONE arena, or the exchange is lost
+        no_decay = "bn"; optim = "sgd"; momentum = 0.9; learning_rate = 1e-3; weight_decay = 5e-4
     dev = torch.device("cuda:0")
     bb = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
     x = fill.closed_form_input(2, 129, 257).to(dev)
@@ -71,6 +73,8 @@ def _child():
         if ddp:
             info["launched"] = model.reducer.launched
             info["chunks"] = len(model.reducer.bounds)
+            info["one_arena"] = optimizer.arena() is model.arena and model.arena.reducer is model.reducer
+        info["groups"] = [len(g["params"]) for g in optimizer.param_groups]
         bufs = {k: v.detach().clone() for k, v in m.state_dict().items()}
         info["table_rebuilds"] = optimizer.table_rebuilds
         return losses, grads, eic, bufs, info
@@ -102,7 +106,8 @@ def test_syncbn_ddp_path_bit_identical_to_plain(cuda):
     assert rec["state_diff"] == [], rec["state_diff"][:8]          # weights after 2 SGD steps, running stats, counters
     assert rec["n_params"] > 150 and rec["nbt"] == 2
     assert rec["info"][1]["launched"] == rec["info"][1]["chunks"] == 3      # the exchange really ran, in 3 all-reduces
-    assert rec["info"][0]["table_rebuilds"] == 1 and rec["info"][1]["table_rebuilds"] == 1   # pointer table built once
+    assert rec["info"][1]["one_arena"] and all(n > 0 for n in rec["info"][1]["groups"]) and len(rec["info"][1]["groups"]) == 2
+    assert rec["info"][0]["table_rebuilds"] == 2 and rec["info"][1]["table_rebuilds"] == 2   # one pointer table per group, built once
 
 
 if __name__ == "__main__" and "--child" in sys.argv:

@@ -116,6 +116,17 @@ def _arena_reducer_mean_of_shard_means(rank, world):
     arena = ParamArena(ps)
     red = GradReducer(arena, None, 3)
     assert len(red.bounds) == 3 and red.bounds[0][2] == 0 and red.bounds[-1][3] == arena.total
+    # arena identity is a matter of the parameter SET: the optimizer walks the parameters by param group, the wrapper in
+    # module order; a different order must find the same arena (and keep its reducer), a different set must not
+    # silently re-home parameters that have a gradient exchange attached
+    assert ParamArena.of(list(reversed(ps))) is arena and arena.reducer is red and arena.covers([ps[2], ps[0], ps[3], ps[1]])
+    assert not arena.covers(ps[:3]) and not arena.covers(ps + [ps[0]])
+    try:
+        ParamArena.of(ps[:2])
+        raise AssertionError("a partial parameter list replaced an arena that has a reducer")
+    except RuntimeError as e:
+        assert "gradient reducer" in str(e)
+    assert all(p._dcfp_slot.arena is arena for p in ps)
 
     def loss_fn(w, b, extra, unused, xs, ys):
         return F.cross_entropy(F.conv2d(xs, w, b), ys, ignore_index=255) + 1e-3 * (extra ** 2).sum() + 0.0 * unused.sum()
@@ -140,6 +151,10 @@ def _arena_reducer_mean_of_shard_means(rank, world):
                 outs.append(grad_commit(p, t, tok))
             return (None,) + tuple(reversed(outs)) + (None,)
     arena.zero_grad()
+    # a backward that died half-way (exception in a later node) must not poison the next step
+    red._active, red.works, red.launched = True, [], 1           # what such a backward leaves behind
+    red.begin_step()
+    assert not red._active and red.launched == 0
     out = Direct.apply(torch.ones((), requires_grad=True), *ps)
     out.backward()
     assert red.launched == 3                                     # the unused range is completed with zeros

@@ -282,8 +282,27 @@ def test_inference_path_vs_oracle(cuda):
     logits = ev.predict_whole(m, x.to(cuda))
     # eval-mode logits with untrained running statistics are O(100): compare relative to their scale
     assert (logits.cpu() - outs[0]).abs().max().item() < 1e-4 * outs[0].abs().max().item()
-    ms = ev.predict_multiscale(m, x.to(cuda), [0.75, 1.0], 19, True, True)
-    assert tuple(ms.shape) == (2, 19, 97, 129) and torch.isfinite(ms).all()
+    # multi-scale + flip, whole-image and sliding-window (evaluate.py:145-227), against the oracle's drivers around the
+    # oracle's forward (same tiles, same flips, same resizes); tolerances relative to the logits' scale as above
+    def onet(im):
+        with torch.no_grad():
+            return [omodel.seg_forward(osd, im, cfg, None, training=False)[0][0]]
+    scale_ = outs[0].abs().max().item()
+    for whole, tile in ((True, (0, 0)), (False, (65, 81))):
+        ms = ev.predict_multiscale(m, x.to(cuda), tile, [0.75, 1.0], 19, True, True, whole)
+        ref_ms = evalmetrics.predict_multiscale(onet, x, tile, [0.75, 1.0], 19, True, True, whole)
+        assert tuple(ms.shape) == (2, 19, 97, 129)
+        assert (ms.cpu() - ref_ms).abs().max().item() < 2e-4 * scale_, (whole, (ms.cpu() - ref_ms).abs().max().item(), scale_)
+    # the tiling / count normalisation / flip logic alone, against the fixture produced by the reference's own functions
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "evalmetrics.npz"))
+    classes, tile = int(g["classes"]), tuple(int(v) for v in g["tile"])
+    img = fill.closed_form_input(2, 56, 75)[:1].to(cuda)
+    pnet = evalmetrics.position_net(classes)
+    assert np.abs(ev.predict_sliding(pnet, img, tile, classes).cpu().numpy() - g["sliding"]).max() < 1e-5
+    assert np.abs(ev.predict_sliding(pnet, img[:, :, :20, :30], tile, classes).cpu().numpy() - g["sliding_small"]).max() < 1e-5
+    for whole in (False, True):
+        got = ev.predict_multiscale(pnet, img, tile, [0.75, 1.0, 1.25], classes, True, True, whole).cpu().numpy()
+        assert np.abs(got - g[f"ms_whole{int(whole)}_align1"]).max() < 2e-5, whole
     pred = ev.predict_labels(m, x.to(cuda)).cpu().numpy()
     ref_pred = outs[0].argmax(1).numpy()
     top2 = outs[0].topk(2, dim=1).values

@@ -130,3 +130,28 @@ def test_gsrl_oracle_matches_reference():
         loss.backward()
         assert abs(float(loss.detach()) - float(g[f"loss:{tag}"])) < 1e-6
         assert np.abs(z0.grad.numpy() - g[f"g0:{tag}"]).max() < 1e-7
+
+
+def test_eval_oracle_vs_reference_golden():
+    """oracle/evalmetrics.py (sliding-window / multi-scale + flip drivers, confusion matrix, mIoU) against the outputs of
+    the reference's own function bodies (evaluate.py:113-117, 145-247, 374-380; tests/golden/evalmetrics.npz)."""
+    from oracle import evalmetrics as em
+    g = _load("evalmetrics.npz")
+    classes, tile = int(g["classes"]), tuple(int(v) for v in g["tile"])
+    img = fill.closed_form_input(2, 56, 75)[:1]
+    net = em.position_net(classes)
+    assert np.array_equal(em.predict_sliding(net, img, tile, classes).numpy(), g["sliding"])
+    assert np.array_equal(em.predict_sliding(net, img[:, :, :20, :30], tile, classes).numpy(), g["sliding_small"])
+    for whole in (False, True):
+        for align in (True, False):
+            out = em.predict_multiscale(net, img, tile, [0.75, 1.0, 1.25], classes, True, align, whole).numpy()
+            assert np.array_equal(out, g[f"ms_whole{int(whole)}_align{int(align)}"]), (whole, align)
+    assert np.array_equal(em.predict_multiscale(net, img, tile, [0.5, 1.0], classes, False, True, False).numpy(), g["ms_noflip"])
+    # the overlap really matters in the fixture: sliding != whole for the position-dependent stand-in network
+    assert np.abs(g["ms_whole0_align1"] - g["ms_whole1_align1"]).max() > 1e-2
+    cm = em.confusion_matrix(g["gt"], g["pred"], 19)
+    assert np.array_equal(cm, g["cm"]) and cm.sum() == len(g["gt"]) and cm[18, 18] == 0 and cm[18, 3] > 0
+    miou, iou = em.mean_iou(cm)
+    assert miou == float(g["miou"]) and np.array_equal(iou, g["iou"])
+    p, r = em.precision_recall(cm)
+    assert p == float(g["precision"]) and r == float(g["recall"])
