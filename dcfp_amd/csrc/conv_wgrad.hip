@@ -393,19 +393,35 @@ splitk_reduce_vec4_kernel(const float* __restrict__ ws, float* __restrict__ dw, 
     reinterpret_cast<f4*>(dw)[i] = s;
 }
 
-// db[c] = sum_{n,p} dy[n,c,p]
-__global__ void __launch_bounds__(256)
+// db[c] = sum_{n,p} dy[n,c,p].  One 1024-thread block per channel (the classifiers have 19: few blocks, so each must
+// keep many loads in flight), 16-byte loads where the rows allow, fixed summation order.
+__global__ void __launch_bounds__(1024)
 bias_grad_kernel(const float* __restrict__ dy, long long dy_nstride, float* __restrict__ db, int N,
-                 int P) {
-    __shared__ float red[4];
+                 int P, int vec) {
+    __shared__ float red[16];
     const int c = blockIdx.x;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int n = 0; n < N; ++n) {
         const float* r = dy + (long long)n * dy_nstride + (long long)c * P;
-        for (int i = threadIdx.x; i < P; i += 256) s += r[i];
+        if (vec) {
+            for (int i = 4 * threadIdx.x; i < P; i += 4096) {
+                const float4 v = *reinterpret_cast<const float4*>(r + i);
+                s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < P; i += 1024) s0 += r[i];
+        }
     }
-    const float t = block_sum_256(s, red);
-    if (threadIdx.x == 0) db[c] = t;
+    float s = wave_sum((s0 + s1) + (s2 + s3));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k];
+        db[c] = t;
+    }
 }
 
 int num_cus() {
@@ -1003,9 +1019,10 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         rc = dcfp_wino_wgrad_run(dy, dyn, dyp, x, (long long)d->Cin * d->H * xp, xp, dw, d->N, d->Cout, d->Cin, d->H, d->W,
                                  d->dil, workspace, workspace_bytes, dcfp_s(stream));
         if (rc) return rc;
+        if (db && dyp != d->Wout) return DCFP_E_UNSUPPORTED;      // (the bias-gradient kernel reads dense rows)
         if (db)
-            hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(256), 0, dcfp_s(stream), dy, dyn, db, d->N,
-                               d->Hout * d->Wout);
+            hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(1024), 0, dcfp_s(stream), dy, dyn, db, d->N,
+                               d->Hout * d->Wout, (int)((d->Hout * d->Wout) % 4 == 0 && dyn % 4 == 0 && dcfp_aligned16(dy)));
         DCFP_RETURN_LAUNCH();
     }
     const Plan pl = make_plan(d);
@@ -1065,9 +1082,11 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
                                static_cast<const float*>(workspace), dw, wn, pl.splits);
         }
     }
+    if (db && p.dy_pitch != d->Wout) return DCFP_E_UNSUPPORTED;   // (the bias-gradient kernel reads dense rows)
     if (db) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(256), 0, dcfp_s(stream),
-                           dy, p.dy_nstride, db, d->N, p.P);
+        hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(1024), 0, dcfp_s(stream),
+                           dy, p.dy_nstride, db, d->N, p.P,
+                           (int)(p.P % 4 == 0 && p.dy_nstride % 4 == 0 && dcfp_aligned16(dy) && p.dy_pitch == d->Wout));
     }
     DCFP_RETURN_LAUNCH();
 }

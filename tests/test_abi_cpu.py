@@ -57,3 +57,27 @@ def test_oracle_not_imported_by_product():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_pitched_buffer_lease_follows_the_graph_lifetime():
+    """ops.owner_pitched: a module's persistent row-pitched buffer is busy exactly while an autograd node holds a lease on
+    it - released by that node's backward or by the node's death (a grad-enabled forward that never reaches backward)."""
+    import gc
+    import types
+    import torch
+    from dcfp_amd import ops
+    owner = types.SimpleNamespace()
+    shape, pitch, dev = (1, 2, 3, 8), 12, torch.device("cpu")
+    v1, lease1 = ops.owner_pitched(owner, shape, pitch, dev)
+    assert lease1 is not None and v1.stride(2) == pitch and tuple(v1.shape) == shape
+    v2, lease2 = ops.owner_pitched(owner, shape, pitch, dev)           # first graph still alive: a fresh buffer, no lease
+    assert lease2 is None and v2.data_ptr() != v1.data_ptr()
+    del lease1                                                         # the graph died without backward
+    gc.collect()
+    v3, lease3 = ops.owner_pitched(owner, shape, pitch, dev)
+    assert v3.data_ptr() == v1.data_ptr() and lease3 is not None
+    lease3.release()                                                   # the normal end: backward ran
+    v4, lease4 = ops.owner_pitched(owner, shape, pitch, dev)
+    assert v4.data_ptr() == v1.data_ptr() and lease4 is not None
+    v5, lease5 = ops.owner_pitched(owner, shape, pitch, dev, track=False)    # no_grad forward: nothing to hold
+    assert lease5 is None

@@ -43,10 +43,10 @@ def _build(backbone, device, closed_form=True):
     return m.to(device).train()
 
 
-def test_config2_iteration_vs_oracle(cuda):
+def _iteration_vs_oracle(backbone, cuda):
     from dcfp_amd import pruners
     N, H, W = 2, 512, 1024
-    m = _build("resnet50", cuda)
+    m = _build(backbone, cuda)
     sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     x = fill.closed_form_input(N, H, W)
     lab = fill.closed_form_labels(N, H, W)
@@ -56,24 +56,38 @@ def test_config2_iteration_vs_oracle(cuda):
     tp.step(m)
     torch.cuda.synchronize()
 
-    cfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
+    cfg = omodel.Cfg(model="deeplabv3", backbone=backbone, align_corner=True)
     cpu = CpuTrainer(sd0, cfg, r=0.999)
     closs, outs, lowres = cpu.step(x, lab, update=False)
     assert abs(loss.item() - closs) <= 2e-5 * max(1.0, abs(closs)), (loss.item(), closs)
 
+    # acceptance as SURVEY.md App. D item 1 states it: error against an fp64 run of the oracle, bounded by 3x the fp32
+    # oracle's own error against that run - per tensor, a tensor whose own fp32 error happens to be tiny being held to the
+    # oracle's worst tensor (R50 at this size: 2e-2; R101, twice as deep: 8e-2 - ReLU masks flip on near-zero
+    # pre-activations, App. D) rather than to a fixed floor
+    cpu64 = CpuTrainer(sd0, cfg, r=0.999, dtype=torch.float64)
+    cpu64.step(x.double(), lab, update=False)
     params = dict(m.named_parameters())
-    worst = []
-    for k, p in cpu.params().items():
-        a = params[k].grad.double().cpu(); b = p.grad.double()
-        worst.append((((a - b).norm() / (b.norm() + 1e-30)).item(), k))
-    worst.sort(reverse=True)
-    assert worst[0][0] <= 5e-2, worst[:5]
+    g32, g64 = cpu.params(), cpu64.params()
+    rows = []
+    for k in g64:
+        b = g64[k].grad
+        mine = ((params[k].grad.double().cpu() - b).norm() / (b.norm() + 1e-30)).item()
+        ref = ((g32[k].grad.double() - b).norm() / (b.norm() + 1e-30)).item()
+        rows.append((mine, ref, k))
+    noise = max(r[1] for r in rows)
+    bad = sorted(((mi / (3 * max(rf, noise)), mi, rf, k) for mi, rf, k in rows if mi > 3 * max(rf, noise)), reverse=True)
+    assert not bad, (noise, bad[:5])
+    assert noise < 0.2, noise                  # (the oracle itself is meaningful at this size)
     # the EIC statistic the pruner consumes
-    mine = torch.cat([tp.get_eic()["eic"][n].reshape(-1) for n in cpu.scored]).cpu().numpy()
-    ref = np.concatenate([np.asarray(cpu.eic[n]).reshape(-1) for n in cpu.scored])
-    assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) <= 5e-2
+    mine = torch.cat([tp.get_eic()["eic"][n].reshape(-1) for n in cpu.scored]).double().cpu().numpy()
+    e32 = np.concatenate([np.asarray(cpu.eic[n], dtype=np.float64).reshape(-1) for n in cpu.scored])
+    e64 = np.concatenate([np.asarray(cpu64.eic[n], dtype=np.float64).reshape(-1) for n in cpu64.scored])
+    rel = np.linalg.norm(mine - e64) / np.linalg.norm(e64)
+    ref_rel = np.linalg.norm(e32 - e64) / np.linalg.norm(e64)
+    assert rel <= 3 * ref_rel, (rel, ref_rel)
     # logits of the same (train-mode) forward: low-resolution heads, before the 8x upsample
-    m2 = _build("resnet50", cuda)
+    m2 = _build(backbone, cuda)
     with torch.no_grad():
         outs2 = m2(x.to(cuda), None, deepsup=True)
     # acceptance as SURVEY.md App. D item 1 states it: error against an fp64 run of the oracle, bounded by
@@ -88,6 +102,28 @@ def test_config2_iteration_vs_oracle(cuda):
         rel = ((mine_o.double().cpu() - ref64).norm() / ref64.norm()).item()
         ref_rel = ((ref32.detach().double() - ref64).norm() / ref64.norm()).item()
         assert rel <= max(1e-4, 3 * ref_rel), (rel, ref_rel)
+
+
+def test_config2_iteration_vs_oracle(cuda):
+    _iteration_vs_oracle("resnet50", cuda)
+
+
+def test_r101_iteration_vs_oracle_at_real_map_sizes(cuda):
+    """DeepLabv3-R101 at 2x3x512x1024 (64 x 128 feature maps): the 23 layer3 blocks, the multi-grid layer4
+    (dilation 4 / 8 / 16, networks/backbone/resnet.py:124-141) and the ASPP branches (dilation 12 / 24 / 36,
+    networks/tools/aspp.py:40-47) run through the kernels the headline config uses - Winograd with its 2d x 2d
+    super-blocks padded (2 * 12, 2 * 24 and 2 * 36 do not divide 64 / 128), the fused Winograd kernel on the pitched
+    layer3 operands, the 256 x 256 LDS-DMA tiles - as one whole iteration against the CPU oracle: loss, every parameter
+    gradient, the EIC vector, low-resolution logits against an fp64 forward (the 2 x 65 x 65 golden has 9 x 9 maps,
+    where none of these engage)."""
+    from dcfp_amd import ops, _lib
+    if WINO:
+        seen = {}
+        for tag, (cin, cout, dil) in {"layer3": (256, 256, 2), "layer4": (512, 512, 4), "aspp": (2048, 256, 12)}.items():
+            desc = ops._desc((2, cin, 64, 128), (cout, cin, 3, 3), 1, dil, dil)
+            seen[tag] = [ops.conv_kernel_name(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)]
+        assert all(any(n.startswith("winograd_f2x2_3x3") for n in names) for names in seen.values()), seen
+    _iteration_vs_oracle("resnet101", cuda)
 
 
 @pytest.fixture(scope="module")
@@ -193,6 +229,8 @@ SLICE_SHAPES = [
     ((4, 1024, 128, 256, 256, 1, 1, 0, 1), ("igemm2_dma1p_kernel", "wgrad_dma_kernel<1,false>")),  # layer3 conv1
     ((4, 2048, 128, 256, 256, 3, 1, 12, 12), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # ASPP
     ((4, 1024, 128, 256, 512, 3, 1, 1, 1), ("igemm2_dma_kernel<9,true>", "wgrad_dma_kernel<9,true>")),    # conv_deepsup.0
+    ((4, 512, 128, 256, 512, 3, 1, 16, 16), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # layer4.2 conv2 (mg_unit 4)
+    ((4, 512, 128, 256, 512, 3, 1, 8, 8), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),    # layer4.1 conv2
     ((4, 64, 512, 1024, 128, 3, 1, 1, 1), (None, None)),                                                  # stem
     ((4, 128, 256, 512, 128, 3, 2, 1, 1), (None, None)),                                                  # layer2.0 conv2 (stride 2)
     ((4, 256, 256, 512, 512, 1, 2, 0, 1), (None, None)),                                                  # layer2.0 downsample (stride 2)
@@ -244,3 +282,81 @@ def test_config3_dgrad_wgrad_vs_fp64_slice(cuda, shape, kernels):
     assert rel(dx[:, ci], rdx) < max(tol, 1e-5), rel(dx[:, ci], rdx)
     assert rel(dxa[:, ci], rdx + seed[:, ci].double()) < max(tol, 1e-5)
     assert rel(dw[:, ci], rdw) < 2e-5, rel(dw[:, ci], rdw)      # N*Ho*Wo-long reduction, split-K in a fixed order
+
+
+# ---------------------------------------------------------------- config 5 at full size: the slim R101
+SLIM_CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "data",
+                        "channel_cfg_r101_p60_synthetic.pth")
+
+
+def test_config5_slim_r101_step_is_bit_reproducible(cuda):
+    """The slim DeepLabv3-R101 of tools/pipeline_cfg5.sh (60 % of the FLOPs pruned, channel counts off every tile grid)
+    at 4x3x1024x2048: one fine-tune step (train.py:200-205 + :255-270) twice from the same state gives the same bits -
+    ragged-M kernels, Winograd on ragged widths and their split-K reductions all have a fixed order."""
+    from dcfp_amd import networks, pruners
+    from dcfp_amd.loss.criterion import build_criterions
+    torch.manual_seed(12345)
+    m = networks.deeplabv3.Seg_Model(backbone="resnet101", backbone_para=dict(BB), num_classes=19, align_corner=True,
+                                     criterion=build_criterions("ce", _DS(), {"ds_weight": 0.4}), deepsup=True)
+    pruners.init_pruned_model(m, torch.load(SLIM_CFG, weights_only=False))
+    m.conv_deepsup[3].p = 0.0
+    m = m.to(cuda).train()
+    widths = sorted({mod.out_channels for mod in m.modules() if isinstance(mod, torch.nn.Conv2d)})
+    assert any(wd % 32 for wd in widths), widths              # really ragged
+    g = torch.Generator().manual_seed(12345)
+    x = torch.randn(4, 3, 1024, 2048, generator=g).to(cuda)
+    lab = torch.randint(0, 19, (4, 1024, 2048), generator=g)
+    lab[torch.rand(lab.shape, generator=g) < 0.05] = 255
+    lab = lab.to(cuda)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    l1, g1 = _step(m, x, lab)
+    m.load_state_dict(sd)
+    l2, g2 = _step(m, x, lab)
+    assert torch.isfinite(l1) and torch.equal(l1, l2), (l1.item(), l2.item())
+    bad = [n for (n, _), a, b in zip(m.named_parameters(), g1, g2) if not torch.equal(a, b)]
+    assert not bad, bad[:5]
+    assert all(torch.isfinite(gr).all() for gr in g1)
+    del m, x, g1, g2
+    torch.cuda.empty_cache()
+
+
+# ragged launch geometries of that slim model (tools/conv_bench.py p_*), all three passes against fp64 on a channel slice
+SLIM_SHAPES = [(4, 236, 128, 256, 232, 3, 1, 2, 2), (4, 204, 128, 256, 188, 3, 1, 2, 2), (4, 2048, 128, 256, 83, 3, 1, 36, 36),
+               (4, 1024, 128, 256, 236, 1, 1, 0, 1)]
+
+
+@pytest.mark.parametrize("shape", SLIM_SHAPES)
+def test_config5_ragged_shapes_vs_fp64_slice(cuda, shape):
+    import math
+    import torch.nn.functional as F
+    from dcfp_amd import ops
+    N, Cin, H, W, Cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = (torch.relu(x) + 0.05 * x).to(cuda)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).to(cuda)
+    dy = (torch.randn(N, Cout, H, W, generator=g) * 1e-2).to(cuda)
+    pitch = ops.conv_pitch(tuple(x.shape), tuple(w.shape), s, p, d)
+    xs, dys = x, dy
+    if pitch:                     # the model hands these convs row-pitched operands
+        xs = ops.new_pitched(tuple(x.shape), pitch, cuda); xs.copy_(x)
+        dys = ops.new_pitched(tuple(dy.shape), pitch, cuda); dys.copy_(dy)
+    y = ops.conv2d_fwd(xs, w, None, s, p, d)
+    dx = ops.conv2d_dgrad(dys, w, tuple(x.shape), s, p, d)
+    dw = ops.conv2d_wgrad(dys, xs, tuple(w.shape), s, p, d)[0]
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return ((a.double() - b).norm() / b.norm()).item()
+    # forward: the LAST output channels (ragged tile) need every input channel
+    co = slice(Cout - min(Cout, 8), Cout)
+    ry = F.conv2d(x.double().cpu(), w[co].double().cpu(), None, s, p, d)
+    tol = 3e-6 * max(1.0, math.sqrt(Cin * k * k) / 8)
+    assert rel(y[:, co].cpu(), ry) < max(tol, 1e-5), rel(y[:, co].cpu(), ry)
+    # dgrad / wgrad: the last input channels need every output channel
+    ci = slice(Cin - min(Cin, 8), Cin)
+    x64 = x[:, ci].double().cpu().requires_grad_(True)
+    w64 = w[:, ci].double().cpu().requires_grad_(True)
+    F.conv2d(x64, w64, None, s, p, d).backward(dy.double().cpu())
+    assert rel(dx[:, ci].cpu(), x64.grad) < max(3e-6 * max(1.0, math.sqrt(Cout * k * k) / 8), 1e-5)
+    assert rel(dw[:, ci].cpu(), w64.grad) < 2e-5

@@ -415,3 +415,31 @@ def test_masked_fanin_bit_identical_to_materialised_residual_gradient(cuda):
 if __name__ == "__main__" and "--fanin-child" in __import__("sys").argv:
     __import__("sys").path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _fanin_child()
+
+
+def test_dropped_graph_releases_the_pitched_buffers(cuda, monkeypatch):
+    """A grad-enabled forward whose graph never runs backward (validation without no_grad, the NaN guard raising,
+    train.py:260) must not leave the Bottlenecks' persistent row-pitched buffers marked busy: the next step would then
+    allocate and zero-fill a fresh activation-sized buffer per block, every step, silently.  (2x3x512x1024: the size
+    from which the dilation-1 / 2 convs take row-pitched operands.)"""
+    from dcfp_amd import ops
+    m = build("deeplabv3", "resnet50", True, cuda)
+    x = fill.closed_form_input(2, 512, 1024).to(cuda)
+    lab = fill.closed_form_labels(2, 512, 1024).to(cuda)
+    m(x, lab, deepsup=True)["loss"].backward()               # first step creates the buffers
+    owners = [mod for mod in m.modules() if getattr(mod, "_dcfp_pitch", None) is not None]
+    assert len(owners) >= 10, len(owners)                    # the Bottlenecks of layer1 .. layer3 own one each
+    calls = []
+    real = ops.new_pitched
+    monkeypatch.setattr(ops, "new_pitched", lambda *a, **k: (calls.append(a[0]), real(*a, **k))[1])
+    loss = m(x, lab, deepsup=True)["loss"]                   # grad-enabled forward ...
+    assert calls == []
+    del loss                                                 # ... whose graph is dropped without backward
+    l2 = m(x, lab, deepsup=True)["loss"]
+    l2.backward()
+    assert calls == [], calls                                # every block found its buffer free again
+    held = m(x, lab, deepsup=True)["loss"]                   # a graph that is still alive keeps its buffers:
+    m(x, lab, deepsup=True)["loss"].backward()               # a second forward meanwhile gets fresh ones
+    assert len(calls) >= len(owners)
+    held.backward()
+    torch.cuda.synchronize()

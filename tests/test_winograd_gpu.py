@@ -15,10 +15,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (N, Cin, H, W, Cout, dilation): even / odd sizes against the 2d x 2d super-blocks, every dilation of the model,
+# (N, Cin, H, W, Cout, dilation): even / odd sizes against the 2d x 2d super-blocks, every dilation of the model (1, 2, 4, 8, 16, 12, 24, 36),
 # column counts whose tile rows need padding to 16-byte quads, one shape per GEMM regime (K = 256 / >= 512)
 SHAPES = [(2, 256, 64, 128, 256, 2), (4, 256, 50, 68, 512, 1), (5, 288, 33, 60, 256, 4), (2, 512, 64, 128, 256, 12),
-          (1, 256, 96, 192, 512, 24), (2, 256, 47, 129, 256, 2)]
+          (1, 256, 96, 192, 512, 24), (2, 256, 47, 129, 256, 2),
+          # layer4's multi-grid dilations (resnet.py:124-141: 8 and 16; 2 * 16 divides the 128-row map exactly, no tile
+          # padding) and the ASPP's 36 (aspp.py:40-47; 2 * 36 does not divide 128 / 256: 27 % of the tiles are padding)
+          (2, 512, 64, 128, 512, 8), (1, 512, 128, 256, 512, 16), (1, 256, 128, 256, 256, 36)]
 
 
 def _child():
