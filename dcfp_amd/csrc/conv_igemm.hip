@@ -67,6 +67,8 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
                   float* stat_part = nullptr, const float* scale = nullptr, const float* shift = nullptr,
                   const float* residual = nullptr, int relu = 0);
 long long dcfp_wino_stat_slots(int N, int H, int W, int d);
+bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_nstride, int pitch);   // conv_winograd2.hip
+size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
 bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d);      // conv_wgrad.hip
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
@@ -102,35 +104,55 @@ static bool igemm3_ok(int M, long long px, int sn, int sd) {
 // profiles/r02_winograd_ab.txt): direct = nominal FLOPs x executed share (dead kernel rows) at 143 TF; Winograd =
 // 16/36 of the nominal FLOPs x tile padding at 118 ... 135 TF (by GEMM shape) plus the two transform passes
 // at 4.2 / 5.4 TB/s.  DCFP_CONV_WINOGRAD: 0 off, 1 model (default), 2 wherever eligible (A/B).
-static bool wino_pass(const DcfpConvDesc* d, int pass) {
+// which Winograd path a pass would take: 0 none (direct kernels), 1 the three passes of conv_winograd.hip, 2 the fused kernel
+// of conv_winograd2.hip (the only one for fewer than 129 / 128 channels; needs a row-pitched operand for dilation 1 / 2)
+static int wino_kind(const DcfpConvDesc* d, int pass) {
     static const int mode = [] { const char* e = getenv("DCFP_CONV_WINOGRAD"); return e ? atoi(e) : 1; }();
-    if (mode == 0) return false;
+    if (mode == 0) return 0;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->Hout != d->H || d->Wout != d->W)
-        return false;
-    if (math_bf16x3()) return false;
+        return 0;
+    if (math_bf16x3()) return 0;
     const bool fwd = pass == DCFP_CONV_FWD;
     const int M = fwd ? d->Cout : d->Cin, Ck = fwd ? d->Cin : d->Cout;
-    if (!dcfp_wino_ok(d->N, d->H, d->W, d->dil, M, Ck)) return false;
-    if (mode == 2) return true;
     const int sp = fwd ? d->x_pitch : d->dy_pitch;
     const bool pitched = sp && sp != d->W;
+    const bool three = dcfp_wino_ok(d->N, d->H, d->W, d->dil, M, Ck);
+    const bool fused = dcfp_wino_fused_ok(d->N, d->H, d->W, d->dil, M, Ck, (long long)Ck * d->H * (sp ? sp : d->W), sp);
+    if (!three && !fused) return 0;
+    if (mode == 2) return three ? 1 : 2;
     const double nominal = 2.0 * d->N * (double)d->H * d->W * (double)M * Ck * 9.0;
     const double f_direct = fwd ? dcfp_igemm2_exec_fraction(9, M, Ck, d->N, d->H, d->W, d->H, d->W, 1, 1, -d->pad, d->dil, pitched)
                                 : dcfp_igemm2_exec_fraction(9, M, Ck, d->N, d->H, d->W, d->H, d->W, 1, 1, d->pad, -d->dil, pitched);
-    // (channel counts off the 256 grid - pruned models - run the ragged-M direct kernel: 100...127 TF measured)
+    // (channel counts off the 256 grid - pruned models, the narrow layers - run the ragged-M / register-staged direct
+    //  kernels: 100...127 TF measured)
     const double t_direct = nominal * f_direct / (M % 256 != 0 ? 115e12 : 143e12);
     const double f_wino = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, M, Ck);
-    const double tiles = f_wino * 9.0 / 16.0 * d->N * (double)d->H * d->W;          // T
-    // batched GEMM rate by shape class (measured): K = 256 is store-bound (118 TF at M = 256, 130 at M >= 1024),
-    // deeper K runs at 127 TF with one row of M tiles and 135 TF with several
-    const double rate = Ck <= 256 ? (M >= 1024 ? 130e12 : 118e12) : (M <= 256 ? 127e12 : 135e12);
-    const double pix = (double)d->N * d->H * d->W;
-    const double t_in = (4.0 * pix * Ck + 64.0 * tiles * Ck) / 4.2e12;
-    const double t_out = (64.0 * tiles * M + 4.0 * pix * M * (fwd ? 1.0 : 2.0)) / 5.4e12;
-    const double mpad = (double)((M + 255) / 256 * 256) / M;      // the GEMM's tiles are 256 (128) rows: ragged M pays for the padding
-    const double t_wino = nominal * f_wino * mpad / rate + t_in + t_out + 20e-6;
-    return t_wino < 0.97 * t_direct;
+    double t_wino = 1e30;
+    if (three) {
+        const double tiles = f_wino * 9.0 / 16.0 * d->N * (double)d->H * d->W;          // T
+        // batched GEMM rate by shape class (measured): K = 256 is store-bound (118 TF at M = 256, 130 at M >= 1024),
+        // deeper K runs at 127 TF with one row of M tiles and 135 TF with several
+        const double rate = Ck <= 256 ? (M >= 1024 ? 130e12 : 118e12) : (M <= 256 ? 127e12 : 135e12);
+        const double pix = (double)d->N * d->H * d->W;
+        const double t_in = (4.0 * pix * Ck + 64.0 * tiles * Ck) / 4.2e12;
+        const double t_out = (64.0 * tiles * M + 4.0 * pix * M * (fwd ? 1.0 : 2.0)) / 5.4e12;
+        const double mpad = (double)((M + 255) / 256 * 256) / M;      // the GEMM's tiles are 256 (128) rows: ragged M pays for the padding
+        t_wino = nominal * f_wino * mpad / rate + t_in + t_out + 20e-6;
+    }
+    if (fused && !three) {
+        // (where the three passes apply their model decides and dcfp_wino_run takes the fused kernel where it wins)
+        // the fused kernel: 115 TF in its K loop, about four K-steps' worth of prologue + epilogue per block (measured
+        // executed rates, profiles/r03_wino_fused_ab.txt: 77 TF at 64 input channels, 96 at 128, 110 at 256, 118 at 1024);
+        // blocks are 64 output channels
+        const double nk = (double)((Ck + 15) / 16 * 2);
+        const double mpad = (double)((M + 63) / 64 * 64) / M;
+        const double t_f = nominal * f_wino * mpad / (115e12 * nk / (nk + 4.0)) + 10e-6;
+        if (t_f < t_wino) t_wino = t_f;
+    }
+    if (!(t_wino < 0.97 * t_direct)) return 0;
+    return three ? 1 : 2;
 }
+static bool wino_pass(const DcfpConvDesc* d, int pass) { return wino_kind(d, pass) != 0; }
 
 extern "C" int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK || pass == DCFP_CONV_WGRAD) return 0;
@@ -139,9 +161,11 @@ extern "C" int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass)
 
 extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK) return 0;
-    if (wino_pass(d, pass))
-        return pass == DCFP_CONV_FWD ? dcfp_wino_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)
-                                     : dcfp_wino_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cin, d->Cout);
+    if (const int wk = wino_kind(d, pass)) {
+        const int M = pass == DCFP_CONV_FWD ? d->Cout : d->Cin, Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
+        return wk == 1 ? dcfp_wino_workspace_bytes(d->N, d->H, d->W, d->dil, M, Ck)
+                       : dcfp_wino_fused_workspace_bytes(d->N, d->H, d->W, d->dil, M, Ck);
+    }
     const int T = d->KH * d->KW;
     size_t b2, b3 = 0;
     if (pass == DCFP_CONV_FWD) {
@@ -161,7 +185,9 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     if (rc) return rc;
     if (!buf || buf_len <= 0) return DCFP_E_BADDESC;
     if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_kernel_name(d, buf, buf_len);
-    if (wino_pass(d, pass)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 (igemm2_dma1p_kernel<false,true>)");
+    if (const int wk = wino_kind(d, pass))
+        return wk == 1 ? snprintf(buf, buf_len, "winograd_f2x2_3x3 (igemm2_dma1p_kernel<false,true>)")
+                       : snprintf(buf, buf_len, "winograd_f2x2_3x3 fused (wino_fused_kernel)");
     const int M = pass == DCFP_CONV_FWD ? d->Cout : d->Cin;
     const long long px = pass == DCFP_CONV_FWD ? (long long)d->N * d->Hout * d->Wout : (long long)d->N * d->H * d->W;
     const int sd = pass == DCFP_CONV_FWD ? 1 : d->stride;
@@ -407,6 +433,10 @@ extern "C" int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d) {
     if (xp < d->W + d->pad && xp != d->W) return 0;
     if (dp < d->Wout + d->pad && dp != d->Wout) return 0;
     const long long pxo = (long long)d->N * d->Hout * d->Wout, pxi = (long long)d->N * d->H * d->W;
+    // forward and dgrad on the fused Winograd kernel (it is what makes the narrow layers Winograd at all - it reads the
+    // shifted operand through 16-byte loads that rely on the zero tail), weight gradient on a kernel that takes the pitch
+    if (xp != d->W && dp != d->Wout && wino_kind(d, DCFP_CONV_FWD) == 2 && wino_kind(d, DCFP_CONV_DGRAD) == 2)
+        return dcfp_wgrad_pitch_ok(d) ? 1 : 0;
     // each of forward / dgrad on the 256 x 256 LDS-DMA kernel or on the ragged-M one (conv_igemm2n.hip)
     if (!dcfp_igemm2_dma_shape(9, d->Cout, d->Cin, d->Hout * d->Wout, pxo, 1, 1, -d->pad, d->H * d->W, d->Wout) &&
         !dcfp_igemm2_use_dma8(9, d->Cout, d->Hout * d->Wout, pxo, 1, 1, -d->pad, d->dil, d->H * d->W, d->Wout, true))

@@ -42,7 +42,7 @@ struct WgradParams {
     int Kpix;
     int kchunk, splits, tiles_m, tiles_n;
     int quad_ok;  // Wo % 4 == 0: the 4 pixels of a quad share (img, oh)
-    int x_pitch, dy_pitch;   // row pitches (floats) of x / dy; > W / Wo: rows carry a zero tail (wgrad_dma_kernel only)
+    int x_pitch, dy_pitch;   // row pitches (floats) of x / dy; > W / Wo: rows carry a zero tail (wgrad_dma_kernel, wgrad2_kernel)
     int batch;               // wgrad_dma_kernel<1>: independent problems in one launch (Winograd: 16 transformed components),
     long long dy_bstride, x_bstride;   // floats between their operands; outputs [split][batch][M][Nn]
 };
@@ -125,6 +125,10 @@ wgrad2_kernel(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x + (long long)img0 * p.x_nstride), 0, kMaxRecords, 0x00020000);
     const int dyn = (int)p.dy_nstride, xn = (int)p.x_nstride;
+    // row pitches (round 3: the narrow 3x3 convs read row-pitched operands too, since their forward / dgrad run on the
+    // fused Winograd kernel, conv_winograd2.hip): rows xp / dyp floats apart, == W / Wo when dense
+    const int xp = p.x_pitch, dyp = p.dy_pitch;
+    const int dyP = p.Ho * dyp;                      // channel stride of dy
 
     // ---- per-thread rows (fixed over the K loop); out-of-range rows are clamped: they only
     // feed output rows / columns that are never stored
@@ -133,10 +137,10 @@ wgrad2_kernel(const WgradParams p) {
     for (int j = 0; j < PA; ++j) {
         int m = m0 + rrow + ROWS * j;
         m = m < p.M ? m : p.M - 1;
-        a_off[j] = m * p.P;
+        a_off[j] = m * dyP;
     }
     int b_coff[PB], b_dh[PB], b_dw[PB];
-    const int HW = p.H * p.W;
+    const int HW = p.H * xp;                         // channel stride of x (xp == W when dense)
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
         int nn = n0 + rrow + ROWS * j;
@@ -147,7 +151,7 @@ wgrad2_kernel(const WgradParams p) {
         const int kw = (TAPS == 9) ? t - kh * 3 : 0;
         b_dh[j] = kh * p.dil - p.pad;
         b_dw[j] = kw * p.dil - p.pad;
-        b_coff[j] = ci * HW + b_dh[j] * p.W + b_dw[j];   // channel + tap shift, relative to (ih, iw)
+        b_coff[j] = ci * HW + b_dh[j] * xp + b_dw[j];    // channel + tap shift, relative to (ih, iw)
     }
 
     // ---- pixel coordinates of this thread's quad, advanced by BK pixels per K-step
@@ -172,10 +176,10 @@ wgrad2_kernel(const WgradParams p) {
         const int q0 = kbase + 4 * kx;
         if (p.quad_ok) {
             q_ok = q0 < kend;        // kchunk % 16 == 0 and Kpix % 4 == 0: a quad is all-or-nothing
-            q_a = c_im * dyn + c_oh * p.Wo + c_ow;
+            q_a = c_im * dyn + c_oh * dyp + c_ow;
             q_ih = c_oh * p.stride;
             q_iw = c_ow * p.stride;
-            q_x = c_im * xn + q_ih * p.W + q_iw;
+            q_x = c_im * xn + q_ih * xp + q_iw;
             c_ow += BK;
             while (c_ow >= p.Wo) { c_ow -= p.Wo; ++c_oh; }
             while (c_oh >= p.Ho) { c_oh -= p.Ho; ++c_im; }
@@ -187,7 +191,7 @@ wgrad2_kernel(const WgradParams p) {
                 const int imabs = q / p.P;
                 const int pq = q - imabs * p.P;
                 const int oh = pq / p.Wo, ow = pq - oh * p.Wo;
-                img[e] = imabs - img0; pp[e] = pq;
+                img[e] = imabs - img0; pp[e] = oh * dyp + ow;
                 ih[e] = oh * p.stride; iw[e] = ow * p.stride;
             }
         }
@@ -253,7 +257,7 @@ wgrad2_kernel(const WgradParams p) {
                     constexpr int e = decltype(e_)::value;
                     const int hh = ih[e] + b_dh[j], ww = iw[e] + b_dw[j];
                     const bool ok = qv[e] && hh >= 0 && ww >= 0 && hh < p.H && ww < p.W;
-                    const unsigned off = ok ? (unsigned)(img[e] * xn + b_coff[j] + ih[e] * p.W + iw[e]) * 4u : kOob;
+                    const unsigned off = ok ? (unsigned)(img[e] * xn + b_coff[j] + ih[e] * xp + iw[e]) * 4u : kOob;
                     breg[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, off, 0, 0));
                 });
             }
@@ -738,7 +742,11 @@ Plan make_plan(const DcfpConvDesc* d) {
                               !(d->KH == 3 && d->pad != d->dil);
         if (eligible) {
             const long long old_rows = (long long)((M + pl.bm - 1) / pl.bm) * pl.bm, new_rows = (long long)((M + 31) / 32) * 32;
-            if (mode == 2 || pl.cfg != 0 || (M % pl.bm != 0 && 10 * new_rows <= 9 * old_rows)) {
+            // (not the narrow 3x3 convs of the stem / layer1 / layer2, which are row-pitched since round 3 - their forward and
+            //  dgrad run on the fused Winograd kernel - and whose lop-sided register-staged tiles measure 82...110 TF
+            //  against 69 TF here)
+            const bool narrow = M <= 128 && Nn <= 1152;
+            if (mode == 2 || (!narrow && (pl.cfg != 0 || (M % pl.bm != 0 && 10 * new_rows <= 9 * old_rows)))) {
                 pl.wide = true; pl.cfg = 0; pl.bm = 256; pl.bn = 256;
             }
         }
@@ -859,11 +867,12 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 
 }  // namespace
 
-// pitched operands: the LDS-DMA kernel only, 3x3 with pad = dil and a tail that covers the column shifts
+// pitched operands: the LDS-DMA kernels and the register-staged wgrad2_kernel (not the bf16x3 split kernel), 3x3 with
+// pad = dil and a tail that covers the column shifts
 bool dcfp_wgrad_pitch_ok(const DcfpConvDesc* d) {
     if (check_desc(d) != DCFP_OK) return false;
     const Plan pl = make_plan(d);
-    if (wgrad3_ok(d, pl.cfg) || !(pl.wide || wgrad_dma_ok(d, pl.cfg))) return false;
+    if (wgrad3_ok(d, pl.cfg)) return false;
     const int xp = d->x_pitch ? d->x_pitch : d->W;
     if (xp != d->W && (d->KH != 3 || d->pad != d->dil || xp < d->W + d->pad)) return false;
     // 31-bit byte offsets relative to the first image of a split: checked in the launcher with the pitched strides

@@ -35,7 +35,8 @@ bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_
 size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                         float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part);
+                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
+                        const float* scale, const float* shift, const float* residual, int relu);
 
 namespace {
 
@@ -476,21 +477,26 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
                   void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
                   const float* scale, const float* shift, const float* residual, int relu) {
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
-    if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck))
-        return DCFP_E_WORKSPACE;
+    if (!workspace || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
     // The fused kernel (conv_winograd2.hip) where it measures faster than the three passes (same-box A/B,
     // profiles/r03_wino_fused_ab.txt): everywhere except (a) a forward that must leave V behind for the weight gradient
     // with more than 256 input channels - the three-pass path has V anyway, the fused kernel writes it on the side at
     // HBM speed (1...5 GB) - and (b) an accumulating dgrad with >= 1024 output channels (short K, the read-modify-write
-    // of the output dominates).  DCFP_WINO_FUSED=2 takes it wherever it applies (tests).
+    // of the output dominates).  Where the three passes do not apply at all (fewer than 129 / 128 channels: the narrow
+    // layers of the stem, layer1, layer2 and of pruned models) the fused kernel is the Winograd path.
+    // DCFP_WINO_FUSED=2 takes it wherever it applies (tests).
     static const int fused_mode = [] { const char* e = getenv("DCFP_WINO_FUSED"); return e ? atoi(e) : 1; }();
-    const bool fused_wins = fused_mode == 2 || (!(xform_out && Ck > 256) && !(accumulate && M >= 1024));
-    if (!scale && fused_wins && dcfp_wino_fused_ok(N, H, W, d, M, Ck, in_nstride, in_pitch) &&
+    const bool three_ok = dcfp_wino_ok(N, H, W, d, M, Ck);
+    const bool fused_wins = fused_mode == 2 || !three_ok || (!(xform_out && Ck > 256) && !(accumulate && M >= 1024));
+    if (fused_wins && dcfp_wino_fused_ok(N, H, W, d, M, Ck, in_nstride, in_pitch) &&
         workspace_bytes >= dcfp_wino_fused_workspace_bytes(N, H, W, d, M, Ck)) {
         if (stat_part && (!dcfp_wino_stat_slots(N, H, W, d) || accumulate)) return DCFP_E_UNSUPPORTED;
         return dcfp_wino_fused_run(in, in_nstride, in_pitch, w, sAm, sAc, flip, out, out_nstride, N, M, Ck, H, W, d,
-                                   accumulate, workspace, workspace_bytes, stream, xform_out, stat_part);
+                                   accumulate, workspace, workspace_bytes, stream, xform_out, stat_part, scale, shift,
+                                   residual, relu);
     }
+    if (!three_ok) return DCFP_E_UNSUPPORTED;
+    if (workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck)) return DCFP_E_WORKSPACE;
     float* U = static_cast<float*>(workspace);
     float* V = xform_out ? xform_out : U + pl.u_floats;
     float* Mb = U + pl.u_floats + pl.v_floats;

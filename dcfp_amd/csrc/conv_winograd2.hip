@@ -54,6 +54,10 @@ struct WinoFusedParams {
     long long out_nstride;
     float* xform_out;       // nullable: V[16][Ck][T16]
     float* stat_part;       // nullable: BatchNorm partials of y, [slot][M][2] = (mean, M2) over 128 outputs
+    const float* scale;     // nullable: inference epilogue y = act(conv * scale[m] + shift[m] (+ residual)) - the eval-mode
+    const float* shift;     // BatchNorm folded into the conv (dcfp_conv2d_fwd_fused_f32_nchw)
+    const float* residual;  // laid out as out
+    int relu;
     int N, M, Ck, H, W, d, TH, TW;
     long long T, T16;
     int mblocks, tblocks, nk;
@@ -504,6 +508,21 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
             }
             const unsigned vo = (m_lane + mr < p.M) ? evoff : kOob;
             const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)mr * HW4);
+            if (p.scale) {      // block-uniform
+                const int mm = m_lane + mr < p.M ? m_lane + mr : p.M - 1;
+                const float sc = p.scale[mm], sf = p.shift[mm];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sf);
+                if (p.residual) {
+                    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0,
+                                                                                            p.out_bytes, 0x00020000);
+                    v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, vo, so, 0));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+            }
             if (acc_out) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, vo, so, 0));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, vo, so, 0);
         });
@@ -516,6 +535,20 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
         const int m = m_lane + (r & 3) + 8 * (r >> 2);
         float o[2][2];
         out_transform(r, o);
+        if (m < p.M && p.scale) {
+            const float sc = p.scale[m], sf = p.shift[m];
+            const float* rs = p.residual ? p.residual + (obase - p.out) + (long long)m * HW : nullptr;
+            const long long offs[2][2] = {{0, d}, {dW, dW + d}};
+            const bool oks[2][2] = {{okr0 && okc0, okr0 && okc1}, {okr1 && okc0, okr1 && okc1}};
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    float t = fmaf(o[rr][cc], sc, sf);
+                    if (rs && oks[rr][cc]) t += rs[offs[rr][cc]];
+                    o[rr][cc] = p.relu ? (t > 0.f ? t : 0.f) : t;
+                }
+        }
         if (m < p.M) {
             float* e = obase + (long long)m * HW;
             if (acc_out) {
@@ -627,7 +660,8 @@ size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck
 
 int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                         float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
-                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part) {
+                        void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
+                        const float* scale, const float* shift, const float* residual, int relu) {
     const FusedPlan pl = fused_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < (size_t)pl.ug_floats * sizeof(float))
         return DCFP_E_WORKSPACE;
@@ -653,6 +687,7 @@ int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, con
     p.out_nstride = out_nstride;
     p.xform_out = xform_out;
     p.stat_part = stat_part;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.N = N; p.M = M; p.Ck = Ck; p.H = H; p.W = W; p.d = d; p.TH = pl.TH; p.TW = pl.TW;
     p.T = pl.T; p.T16 = pl.T16;
     p.mblocks = pl.mblocks; p.tblocks = pl.tblocks; p.nk = pl.nk;

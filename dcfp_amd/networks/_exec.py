@@ -126,16 +126,18 @@ def bottleneck(blk, x):
     return ops.bottleneck(x, cfg, tensors)
 
 
-def run_sequential(seq, x):
+def run_sequential(seq, x, tail_conv=None):
     """Interpret an nn.Sequential of the reference (stem, downsample, heads, image-pool branch)
-    with conv -> (BN [+ReLU]) peephole fusion."""
+    with conv -> (BN [+ReLU]) peephole fusion.  tail_conv: the conv module the caller runs on the result."""
     mods = list(seq.children())
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], _BN_TYPES):
             fuse = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-            nxt = mods[i + 3] if fuse and i + 3 < len(mods) else None     # conv -> BN -> ReLU -> conv: y feeds it directly
+            nxt = None                                                    # conv -> BN -> ReLU -> conv: y feeds it directly
+            if fuse:
+                nxt = mods[i + 3] if i + 3 < len(mods) else (tail_conv if i + 3 == len(mods) else None)
             x = conv_bn_act(m, mods[i + 1], x, relu=fuse, next_conv=nxt if isinstance(nxt, nn.Conv2d) else None)
             i += 2 if fuse else 1
         elif isinstance(m, nn.Conv2d):

@@ -81,7 +81,7 @@ class ResNet(nn.Module):
     def forward(self, input):
         _exec.require_device(input)
         stem = list(self.conv1.children())
-        x = _exec.run_sequential(nn.Sequential(*stem[:-1]), input)
+        x = _exec.run_sequential(nn.Sequential(*stem[:-1]), input, tail_conv=stem[-1])   # (its input row-pitched where it wants that)
         x = _exec.conv_bn_act(stem[-1], self.bn1, x, relu=True)
         x = ops.maxpool3x3s2(x)
         outs = []

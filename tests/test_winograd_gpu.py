@@ -145,6 +145,67 @@ def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
                                                                                              rec["wgrad_rel"], ref["wgrad_rel"])
 
 
+# narrow 3x3 convs (stem 64 -> 64 -> 128, layer1 / layer2 conv2: resnet.py:88-96, 107-122) and ragged pruned widths: below
+# the three-pass path's 129 / 128-channel floor, Winograd through the fused kernel only - forward and dgrad on row-pitched
+# operands, weight gradient on the register-staged direct kernel reading the same pitched tensors
+# (sizes from which the cost model prefers Winograd: a launch of a few GFLOP)
+NARROW = [(2, 64, 128, 256, 64, 1), (2, 64, 96, 160, 128, 1), (3, 128, 64, 128, 128, 1), (2, 100, 64, 128, 120, 2), (2, 72, 96, 160, 200, 4)]
+
+
+@pytest.mark.parametrize("shape", NARROW)
+def test_narrow_layers_on_the_fused_winograd_kernel(cuda, shape):
+    import torch
+    import torch.nn.functional as F
+    from dcfp_amd import _lib, ops
+    if os.environ.get("DCFP_CONV_WINOGRAD", "1") == "0" or os.environ.get("DCFP_WINO_FUSED", "1") == "0":
+        pytest.skip("Winograd / fused kernel switched off")
+    N, Cin, H, W, Cout, d = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = torch.relu(x) + 0.05 * x
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    pitch = ops.conv_pitch(tuple(x.shape), tuple(w.shape), 1, d, d)
+    assert (pitch > 0) == (d <= 2), (shape, pitch)            # dilation 1 / 2 take the pitch, dilation 4 reads dense rows
+    xs, dys = x.to(cuda), dy.to(cuda)
+    if pitch:
+        xs = ops.new_pitched(tuple(x.shape), pitch, cuda); xs.copy_(x.to(cuda))
+        dys = ops.new_pitched(tuple(dy.shape), pitch, cuda); dys.copy_(dy.to(cuda))
+    desc = ops._desc(x.shape, w.shape, 1, d, d, pitch, pitch)
+    names = [ops.conv_kernel_name(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)]
+    assert names[0].startswith("winograd_f2x2_3x3 fused") and names[1].startswith("winograd_f2x2_3x3 fused"), names
+    assert not names[2].startswith("winograd"), names
+    wd = w.to(cuda)
+    y, st = ops.conv2d_fwd(xs, wd, None, 1, d, d, want_stats=True)
+    dx = ops.conv2d_dgrad(dys, wd, tuple(x.shape), 1, d, d)
+    seed = torch.randn(x.shape, generator=g).to(cuda)
+    acc = seed.clone()
+    ops.conv2d_dgrad(dys, wd, tuple(x.shape), 1, d, d, out=acc, accumulate=True)
+    dw = ops.conv2d_wgrad(dys, xs, tuple(w.shape), 1, d, d)[0]
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+    refdx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
+    refdw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, d, d)
+
+    def emax(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max())
+    tol = 3e-6 * max(1.0, math.sqrt(9 * Cin) / 8)
+    assert emax(y, ref) < tol and emax(dx, refdx) < 3e-6 * max(1.0, math.sqrt(9 * Cout) / 8), (emax(y, ref), emax(dx, refdx))
+    assert emax(acc, refdx + seed.cpu().double()) < 3e-6 * max(1.0, math.sqrt(9 * Cout) / 8)
+    assert emax(dw, refdw) < 2e-5, emax(dw, refdw)
+    if st is not None:
+        m_ref, v_ref = ops.bn_stats(y)
+        assert float((st[0] - m_ref).abs().max() / m_ref.abs().max()) < 2e-5
+        assert float(((st[1] - v_ref).abs() / v_ref).max()) < 2e-5
+    # inference: the folded BatchNorm (+residual) (+ReLU) rides on the fused kernel's epilogue (dense input, dilation 4)
+    if not pitch:
+        sc = (torch.rand(Cout, generator=g) + 0.5).to(cuda); sh = (torch.randn(Cout, generator=g) * 0.2).to(cuda)
+        rs = torch.randn(N, Cout, H, W, generator=g).to(cuda)
+        yf = ops.conv2d_fused_infer(x.to(cuda), wd, sc, sh, 1, d, d, rs, True)
+        reff = torch.relu(ref * sc.cpu().double()[None, :, None, None] + sh.cpu().double()[None, :, None, None] + rs.cpu().double())
+        assert emax(yf, reff) < 3e-6
+
+
 def test_direct_conv_kernels_still_covered_with_winograd_off(cuda):
     """The direct 9-tap kernels keep their shapes in the model (dilation-36 forward, channel counts below 256,
     pruned widths, DCFP_CONV_WINOGRAD=0): their test files and the whole-model golden test run once more with the
