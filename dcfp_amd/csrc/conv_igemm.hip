@@ -139,8 +139,9 @@ static int wino_kind(const DcfpConvDesc* d, int pass) {
         const double mpad = (double)((M + 255) / 256 * 256) / M;      // the GEMM's tiles are 256 (128) rows: ragged M pays for the padding
         t_wino = nominal * f_wino * mpad / rate + t_in + t_out + 20e-6;
     }
-    if (fused && !three) {
-        // (where the three passes apply their model decides and dcfp_wino_run takes the fused kernel where it wins)
+    if (fused && (!three || M % 256 != 0)) {
+        // (on the 256 grid the three-pass model decides - and dcfp_wino_run takes the fused kernel where it wins; off it -
+        //  narrow layers, pruned widths - the fused kernel pads M to 64 instead of 256)
         // the fused kernel: 115 TF in its K loop, about four K-steps' worth of prologue + epilogue per block (measured
         // executed rates, profiles/r03_wino_fused_ab.txt: 77 TF at 64 input channels, 96 at 128, 110 at 256, 118 at 1024);
         // blocks are 64 output channels

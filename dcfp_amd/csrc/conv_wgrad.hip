@@ -745,7 +745,7 @@ Plan make_plan(const DcfpConvDesc* d) {
             // (not the narrow 3x3 convs of the stem / layer1 / layer2, which are row-pitched since round 3 - their forward and
             //  dgrad run on the fused Winograd kernel - and whose lop-sided register-staged tiles measure 82...110 TF
             //  against 69 TF here)
-            const bool narrow = M <= 128 && Nn <= 1152;
+            const bool narrow = d->KH == 3 && M <= 128 && Nn <= 1152;
             if (mode == 2 || (!narrow && (pl.cfg != 0 || (M % pl.bm != 0 && 10 * new_rows <= 9 * old_rows)))) {
                 pl.wide = true; pl.cfg = 0; pl.bm = 256; pl.bn = 256;
             }

@@ -238,14 +238,19 @@ def test_ragged_m_kernel(cuda, case, kernels):
         dyin = ops.new_pitched(tuple(dy.shape), pitch, cuda); dyin.copy_(dy)
     desc = ops._desc(x.shape, w.shape, 1, p, d, pitch, pitch)
     for want, which in zip(kernels, (_lib.CONV_FWD, _lib.CONV_DGRAD)):
-        if want is not None:
-            assert ops.conv_kernel_name(desc, which) == want, ops.conv_kernel_name(desc, which)
+        if want is not None:      # (ragged 3x3 shapes the fused Winograd kernel takes since round 3: 64-row blocks; the
+            name = ops.conv_kernel_name(desc, which)     # direct ragged-M kernel is covered with DCFP_CONV_WINOGRAD=0)
+            assert name == want or (WINO and k == 3 and name.startswith("winograd_f2x2_3x3 fused")), name
     y = ops.conv2d_fwd(xin, w, None, 1, p, d)
     y_again = ops.conv2d_fwd(xin, w, None, 1, p, d)              # second call: cached (permuted) Wp, wp_valid = 1
     assert torch.equal(y, y_again)
     bias = torch.randn(Cout, generator=g).to(cuda)               # the classifiers' bias goes through the same epilogue
     yb = ops.conv2d_fwd(xin, w, bias, 1, p, d)
-    assert (yb - (y + bias.view(1, -1, 1, 1))).abs().max().item() <= 1e-6 * max(1.0, yb.abs().max().item())
+    # (same kernel for both where the conv is direct: 1e-6; a 3x3 conv without bias may run as Winograd since round 3,
+    #  with bias never - two fp32 algorithms then, each within the stated conv tolerance of the exact result)
+    same = ops.conv_kernel_name(desc, _lib.CONV_FWD).startswith("igemm2")
+    btol = 1e-6 if same else 2 * 3e-6 * max(1.0, math.sqrt(Cin * k * k) / 8)
+    assert (yb - (y + bias.view(1, -1, 1, 1))).abs().max().item() <= btol * max(1.0, yb.abs().max().item())
     dx = ops.conv2d_dgrad(dyin, w, tuple(x.shape), 1, p, d)
     seed = torch.randn(x.shape, generator=g).to(cuda)
     dxa = seed.clone()

@@ -428,7 +428,7 @@ def test_dropped_graph_releases_the_pitched_buffers(cuda, monkeypatch):
     lab = fill.closed_form_labels(2, 512, 1024).to(cuda)
     m(x, lab, deepsup=True)["loss"].backward()               # first step creates the buffers
     owners = [mod for mod in m.modules() if getattr(mod, "_dcfp_pitch", None) is not None]
-    assert len(owners) >= 10, len(owners)                    # the Bottlenecks of layer1 .. layer3 own one each
+    assert len(owners) >= 5, len(owners)                     # stem BatchNorms and Bottlenecks whose 3x3 conv reads a pitched y1
     calls = []
     real = ops.new_pitched
     monkeypatch.setattr(ops, "new_pitched", lambda *a, **k: (calls.append(a[0]), real(*a, **k))[1])

@@ -149,7 +149,7 @@ def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
 # the three-pass path's 129 / 128-channel floor, Winograd through the fused kernel only - forward and dgrad on row-pitched
 # operands, weight gradient on the register-staged direct kernel reading the same pitched tensors
 # (sizes from which the cost model prefers Winograd: a launch of a few GFLOP)
-NARROW = [(2, 64, 128, 256, 64, 1), (2, 64, 96, 160, 128, 1), (3, 128, 64, 128, 128, 1), (2, 100, 64, 128, 120, 2), (2, 72, 96, 160, 200, 4)]
+NARROW = [(2, 64, 128, 256, 64, 1), (2, 64, 96, 160, 128, 1), (3, 128, 64, 128, 128, 1), (4, 100, 64, 128, 120, 2), (2, 96, 96, 160, 200, 4)]
 
 
 @pytest.mark.parametrize("shape", NARROW)
