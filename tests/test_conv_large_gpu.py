@@ -240,7 +240,7 @@ def test_ragged_m_kernel(cuda, case, kernels):
     for want, which in zip(kernels, (_lib.CONV_FWD, _lib.CONV_DGRAD)):
         if want is not None:      # (ragged 3x3 shapes the fused Winograd kernel takes since round 3: 64-row blocks; the
             name = ops.conv_kernel_name(desc, which)     # direct ragged-M kernel is covered with DCFP_CONV_WINOGRAD=0)
-            assert name == want or (WINO and k == 3 and name.startswith("winograd_f2x2_3x3 fused")), name
+            assert name == want or (WINO and k == 3 and name.startswith("winograd_f2x2_3x3")), name
     y = ops.conv2d_fwd(xin, w, None, 1, p, d)
     y_again = ops.conv2d_fwd(xin, w, None, 1, p, d)              # second call: cached (permuted) Wp, wp_valid = 1
     assert torch.equal(y, y_again)
