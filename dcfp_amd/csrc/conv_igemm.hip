@@ -67,6 +67,11 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
                   float* stat_part = nullptr, const float* scale = nullptr, const float* shift = nullptr,
                   const float* residual = nullptr, int relu = 0);
 long long dcfp_wino_stat_slots(int N, int H, int W, int d);
+bool dcfp_gemv_shape(const DcfpConvDesc* d);                                                            // conv_gemv.hip
+int dcfp_gemv_fwd(const DcfpConvDesc* d, const float* x, const float* w, const float* bias, float* y, long long y_nstride,
+                  hipStream_t stream);
+int dcfp_gemv_dgrad(const DcfpConvDesc* d, const float* dy, long long dy_nstride, const float* w, float* dx, int accumulate,
+                    hipStream_t stream);
 bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_nstride, int pitch);   // conv_winograd2.hip
 size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
@@ -185,6 +190,7 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     int rc = check_desc(d);
     if (rc) return rc;
     if (!buf || buf_len <= 0) return DCFP_E_BADDESC;
+    if (dcfp_gemv_shape(d)) return snprintf(buf, buf_len, "gemv_1x1_map_kernel");
     if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_kernel_name(d, buf, buf_len);
     if (const int wk = wino_kind(d, pass))
         return wk == 1 ? snprintf(buf, buf_len, "winograd_f2x2_3x3 (igemm2_dma1p_kernel<false,true>)")
@@ -271,6 +277,7 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     if (!x || !w || !y) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
     if (d->x_pitch && d->x_pitch != d->W && math_bf16x3()) return DCFP_E_UNSUPPORTED;
+    if (dcfp_gemv_shape(d)) return dcfp_gemv_fwd(d, x, w, bias, y, y_nstride, dcfp_s(stream));
     if (!bias && wino_pass(d, DCFP_CONV_FWD))
         return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T,
                              0, y, y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout,
@@ -327,6 +334,7 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (!dy || !w || !dx) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
     if (d->dy_pitch && d->dy_pitch != d->Wout && math_bf16x3()) return DCFP_E_UNSUPPORTED;
+    if (dcfp_gemv_shape(d)) return dcfp_gemv_dgrad(d, dy, dy_nstride, w, dx, accumulate ? 1 : 0, dcfp_s(stream));
     if (wino_pass(d, DCFP_CONV_DGRAD))      // dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees
         return dcfp_wino_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * (d->dy_pitch ? d->dy_pitch : d->Wout),
                              d->dy_pitch, w, T, d->Cin * T, 1, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin, d->Cout,

@@ -867,6 +867,9 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 
 }  // namespace
 
+bool dcfp_gemv_shape(const DcfpConvDesc* d);     // conv_gemv.hip
+int dcfp_gemv_wgrad(const DcfpConvDesc* d, const float* dy, long long dy_nstride, const float* x, float* dw, hipStream_t stream);
+
 // pitched operands: the LDS-DMA kernels and the register-staged wgrad2_kernel (not the bf16x3 split kernel), 3x3 with
 // pad = dil and a tail that covers the column shifts
 bool dcfp_wgrad_pitch_ok(const DcfpConvDesc* d) {
@@ -1022,6 +1025,8 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !x || !dw) return DCFP_E_BADDESC;
+    if (dcfp_gemv_shape(d) && !db)      // a 1x1 conv on a 1 x 1 map (ASPP image pool): conv_gemv.hip
+        return dcfp_gemv_wgrad(d, dy, dy_nstride, x, dw, dcfp_s(stream));
     if (wino_wgrad_pass(d)) {
         const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout, xp = d->x_pitch ? d->x_pitch : d->W;
         const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;

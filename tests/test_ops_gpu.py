@@ -467,3 +467,34 @@ def test_bn_relu_bitmask_path(cuda):
     dxa, dra = ops.bn_bwd_apply(dy, x, y_ref, mean, var, gamma, beta, 1e-5, s1a, s2a, cnt, 1, True)
     dxb, drb = ops.bn_bwd_apply(dy, x, mask, mean, var, gamma, beta, 1e-5, s1a, s2a, cnt, 3, True)
     assert torch.equal(dxa, dxb) and torch.equal(dra, drb)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,bias", [(4, 2048, 256, False), (10, 100, 37, True), (2, 83, 256, False)])
+def test_conv1x1_on_a_1x1_map_gemv(cuda, N, Cin, Cout, bias):
+    """The ASPP image-pool branch's 1x1 conv runs on an N x C x 1 x 1 tensor (aspp.py:56-61): matrix-vector kernels
+    (conv_gemv.hip) for forward, dgrad (+accumulate) and weight gradient, against fp64."""
+    from dcfp_amd import _lib, ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, Cin, 1, 1, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    dy = torch.randn(N, Cout, 1, 1, generator=g)
+    desc = ops._desc(x.shape, w.shape, 1, 0, 1)
+    assert ops.conv_kernel_name(desc, _lib.CONV_FWD) == "gemv_1x1_map_kernel"
+    y = ops.conv2d_fwd(x.to(cuda), w.to(cuda), None if b is None else b.to(cuda), 1, 0, 1)
+    dx = ops.conv2d_dgrad(dy.to(cuda), w.to(cuda), tuple(x.shape), 1, 0, 1)
+    seed = torch.randn(x.shape, generator=g).to(cuda)
+    acc = seed.clone()
+    ops.conv2d_dgrad(dy.to(cuda), w.to(cuda), tuple(x.shape), 1, 0, 1, out=acc, accumulate=True)
+    dw, db = ops.conv2d_wgrad(dy.to(cuda), x.to(cuda), tuple(w.shape), 1, 0, 1, need_bias=bias)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double())
+    refdx = torch.einsum("nm,mc->nc", dy.double().view(N, Cout), w.double().view(Cout, Cin)).view(N, Cin, 1, 1)
+    refdw = torch.einsum("nm,nc->mc", dy.double().view(N, Cout), x.double().view(N, Cin)).view(Cout, Cin, 1, 1)
+
+    def emax(a, r):
+        return float((a.cpu().double() - r).abs().max() / r.abs().max())
+    assert emax(y, ref) < 3e-6 and emax(dx, refdx) < 3e-6 and emax(acc, refdx + seed.cpu().double()) < 3e-6
+    assert emax(dw, refdw) < 3e-6
+    if bias:
+        assert emax(db, dy.double().sum((0, 2, 3))) < 3e-6
