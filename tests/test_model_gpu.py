@@ -428,6 +428,8 @@ def test_dropped_graph_releases_the_pitched_buffers(cuda, monkeypatch):
     lab = fill.closed_form_labels(2, 512, 1024).to(cuda)
     m(x, lab, deepsup=True)["loss"].backward()               # first step creates the buffers
     owners = [mod for mod in m.modules() if getattr(mod, "_dcfp_pitch", None) is not None]
+    if os.environ.get("DCFP_CONV_WINOGRAD", "1") == "0" and not owners:
+        pytest.skip("direct kernels only: nothing is row-pitched at this size")
     assert len(owners) >= 5, len(owners)                     # stem BatchNorms and Bottlenecks whose 3x3 conv reads a pitched y1
     calls = []
     real = ops.new_pitched
