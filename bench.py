@@ -305,6 +305,9 @@ def main():
                     help="seconds the --gpus N parent waits for its ranks before it stops them and reports")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in SyncBN+DDP and run the collectives even at world size 1 (rehearsal)")
+    ap.add_argument("--syncbn-p2p", action="store_true",
+                    help="data-parallel runs: SyncBN statistics through the peer-to-peer exchange kernel "
+                         "(dcfp_amd/syncbn_p2p.py) instead of one RCCL collective per layer; off by default")
     args, _ = ap.parse_known_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
@@ -333,6 +336,8 @@ def main():
         os.environ["DCFP_FORCE_SYNCBN"] = "1"
         dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     H, W = [int(v) for v in args.size.split(",")]
+    if args.syncbn_p2p:
+        os.environ["DCFP_SYNCBN_P2P"] = "1"
 
     from dcfp_amd import optimizer as opt, pruners, ops
     from dcfp_amd.engine import Engine
@@ -402,13 +407,15 @@ def main():
             # data-parallel step: what the collectives cost where they are exposed.  The 115 forward SyncBN all-gathers sit
             # on the compute stream (HIP-event time of each); the gradient all-reduces are overlapped with backward - what
             # is left of them is the wait at the end of backward; `alone` = the same all-reduces with nothing to overlap.
-            sync = [ms for (kind, _, _, ms) in recs if kind == "syncbn_allgather"]
+            kinds = ("syncbn_allgather", "syncbn_p2p_fwd")
+            sync = [ms for (kind, _, _, ms) in recs if kind in kinds]
             exposed = reducer.exposed_ms()
             alone = reducer.alone_ms()
             comm = {"syncbn_exposed_ms": sum(sync), "syncbn_allgathers": len(sync),
+                    "syncbn_exchange": "p2p kernel" if any(r[0] == "syncbn_p2p_fwd" for r in recs) else "rccl",
                     "grad_allreduce_ms": alone, "grad_allreduce_exposed_ms": exposed,
                     "allreduce_overlapped_frac": (1.0 - exposed / alone) if (alone and exposed is not None) else None}
-            recs = [r for r in recs if r[0] != "syncbn_allgather"]
+            recs = [r for r in recs if r[0] not in kinds]
         if rank == 0:
             roof, extra = roofline_from_profile(recs, args.batch, step_s)
     fence()
@@ -476,6 +483,10 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if dist.is_initialized():
+        from dcfp_amd import syncbn_p2p
+        for px in list(syncbn_p2p._ACTIVE.values()):
+            px.check()                 # an exchange that gave up on a peer is an error, not a number
+        syncbn_p2p.disable()
         dist.destroy_process_group()
 
 

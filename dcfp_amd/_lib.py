@@ -80,6 +80,14 @@ SIGNATURES = {
                                     _P, _Z, _P]),
     "dcfp_bn_update_running_f32": (_I, [_P, _P, _I, _F, _F, _P, _P, _P, _P]),
     "dcfp_syncbn_combine_f32": (_I, [_P, _I, _I, _P, _P, _P, _R, _P]),
+    "dcfp_syncbn_p2p_mailbox_bytes": (_Z, [_I, _I]),
+    "dcfp_p2p_alloc": (_I, [_Z, _I, C.POINTER(C.c_void_p)]),
+    "dcfp_p2p_free": (_I, [_P]),
+    "dcfp_p2p_export": (_I, [_P, _P]),
+    "dcfp_p2p_import": (_I, [_P, C.POINTER(C.c_void_p)]),
+    "dcfp_p2p_unmap": (_I, [_P]),
+    "dcfp_syncbn_p2p_exchange_f32": (_I, [C.POINTER(C.c_void_p), _I, _I, C.c_uint32, _I, _P, _I, _I, _P, _R,
+                                          C.c_uint32, _P, _P]),
     "dcfp_bn_apply_relu_mask_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "dcfp_conv2d_fwd_stat_slots": (_L, [_D, _P, _L]),
     "dcfp_conv2d_fwd_stats_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _P, _Z, _I, _P]),

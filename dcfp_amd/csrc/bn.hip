@@ -17,16 +17,6 @@ __device__ __forceinline__ float bn_val(float v, float mu, float istd, float g, 
     return fmaf((v - mu) * istd, g, b);
 }
 
-// nn.BatchNorm2d's training-mode bookkeeping for channel c, done by the thread that finalises it
-__device__ __forceinline__ void running_update(const DcfpBnRunning& r, int c, float mean, float var, float n) {
-    if (r.running_mean) {
-        const float unb = n / fmaxf(n - 1.0f, 1.0f);
-        r.running_mean[c] = r.running_mean[c] * (1.0f - r.momentum) + r.momentum * mean;
-        r.running_var[c] = r.running_var[c] * (1.0f - r.momentum) + r.momentum * (var * unb);
-    }
-    if (c == 0 && r.num_batches_tracked) r.num_batches_tracked[0] += 1;
-}
-
 struct BnPlan {
     int chunks;       // blocks per channel
     int chunk_elems;  // elements (of the N*HW per-channel population) per block, multiple of 4
@@ -373,9 +363,8 @@ __global__ void bn_running_kernel(int C, const float* __restrict__ mean, const f
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float n = count_dev ? count_dev[0] : count;
-    const float unb = n / fmaxf(n - 1.0f, 1.0f);
-    rmean[c] = rmean[c] * (1.0f - momentum) + momentum * mean[c];
-    rvar[c] = rvar[c] * (1.0f - momentum) + momentum * (var[c] * unb);
+    const DcfpBnRunning r = {rmean, rvar, nullptr, momentum, 0};
+    running_update(r, c, mean[c], var[c], n);      // (one rounding recipe for every kernel: common.h)
 }
 
 // ---- backward stage 2

@@ -46,3 +46,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* smem /* >= 4 floa
     __syncthreads();
     return r;
 }
+
+// nn.BatchNorm2d's training-mode bookkeeping for channel c, done by the thread that finalises it (bn.hip, syncbn_p2p.hip)
+__device__ __forceinline__ void running_update(const DcfpBnRunning& r, int c, float mean, float var, float n) {
+    if (r.running_mean) {
+        // every product and sum rounded on its own (hipcc contracts a*b + c*d into an FMA either way round, and the
+        // __f*_rn intrinsics do not stop it): the kernels that end in this update - per-rank statistics, the SyncBN
+        // combine, the peer-to-peer exchange - must leave the same bits
+#pragma clang fp contract(off)
+        const float unb = n / fmaxf(n - 1.0f, 1.0f);
+        const float keep = 1.0f - r.momentum;
+        const float a = r.running_mean[c] * keep, b = r.momentum * mean;
+        r.running_mean[c] = a + b;
+        const float vu = var * unb;
+        const float d = r.running_var[c] * keep, e = r.momentum * vu;
+        r.running_var[c] = d + e;
+    }
+    if (c == 0 && r.num_batches_tracked) r.num_batches_tracked[0] += 1;
+}

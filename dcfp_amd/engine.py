@@ -8,6 +8,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import syncbn_p2p
 from .utils.pyt_utils import all_reduce_tensor
 
 
@@ -113,6 +114,9 @@ class Engine(object):
                     model, device_ids=ids, output_device=self.local_rank if ids else None,
                     bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
             model = DataParallel(model, n_chunks=n_chunks)
+            if syncbn_p2p.wanted() and torch.cuda.is_available():
+                # opt-in (DCFP_SYNCBN_P2P=1): the 230 per-layer SyncBN collectives become single peer-to-peer kernels
+                syncbn_p2p.enable(dist.group.WORLD, torch.device("cuda", torch.cuda.current_device()))
         return model
 
     def all_reduce_tensor(self, tensor, norm=True):

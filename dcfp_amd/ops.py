@@ -11,7 +11,7 @@ import weakref
 import torch
 import torch.distributed as dist
 
-from . import _lib, arena
+from . import _lib, arena, syncbn_p2p
 from ._lib import ConvDesc, BnRunning, check
 
 _ws_cache = {}
@@ -673,6 +673,11 @@ def sync_bn_stats(mean, var, count, group, run=None, running=None):
     Cc = mean.numel()
     world = dist.get_world_size(group)
     local = torch.cat([mean, var, _count_tensor(count, mean.device)])
+    px = syncbn_p2p.for_group(group) if mean.is_cuda else None
+    if px is not None:       # one launch: peer-to-peer gather + the same rank-order fp64 combination
+        out = torch.empty(2 * Cc + 1, device=mean.device, dtype=torch.float32)
+        _timed("syncbn_p2p_fwd", None, 4.0 * local.numel() * world, lambda: px.exchange(local, out, 2, _rp(run)))
+        return out[:Cc], out[Cc:2 * Cc], out[2 * Cc:]
     allv = torch.empty(world, local.numel(), device=mean.device, dtype=mean.dtype)
     # (exposed on the compute stream: the normalisation that follows needs the pooled statistics; bench.py sums these)
     if mean.is_cuda:
@@ -704,8 +709,19 @@ def sync_bn_bwd_sums(s1, s2, group, async_op=False):
     async_op: returns (s1, s2, work) with the exchange in flight on the collective's stream - the caller
     enqueues independent kernels (a weight gradient) and calls work.wait() before it reads the sums."""
     Cc = s1.numel()
-    if (s1.is_contiguous() and s2.is_contiguous() and s1.untyped_storage().data_ptr() == s2.untyped_storage().data_ptr()
-            and s2.storage_offset() == s1.storage_offset() + Cc):
+    adjacent = (s1.is_contiguous() and s2.is_contiguous()
+                and s1.untyped_storage().data_ptr() == s2.untyped_storage().data_ptr()
+                and s2.storage_offset() == s1.storage_offset() + Cc)
+    px = syncbn_p2p.for_group(group) if s1.is_cuda else None
+    if px is not None:       # one launch: peer-to-peer gather + sum in rank order (identical on every rank)
+        both = s1.as_strided((2 * Cc,), (1,), s1.storage_offset()) if adjacent else torch.cat([s1, s2])
+        out = torch.empty_like(both)
+        if async_op:
+            work = px.exchange_async(both, out, 1)
+            return out[:Cc], out[Cc:], work
+        _timed("syncbn_p2p_bwd", None, 8.0 * Cc * px.world, lambda: px.exchange(both, out, 1))
+        return out[:Cc], out[Cc:]
+    if adjacent:
         both = s1.as_strided((2 * Cc,), (1,), s1.storage_offset())
         work = dist.all_reduce(both, group=group, async_op=async_op)
         return (s1, s2, work) if async_op else (s1, s2)

@@ -241,6 +241,32 @@ int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t slots, int sl
 int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean, float* var,
                             float* total_count, const DcfpBnRunning* run /* nullable; pooled statistics and
                             count */, dcfp_stream_t stream);
+/* SyncBatchNorm exchange without a collective library call (engine.py:65; SURVEY C2: 115 all-gathers + 115
+ * all-reduces of <= 4097 floats per step, all latency-bound): each rank owns a MAILBOX in its HBM that its peers map
+ * (dcfp_p2p_export -> the 64-byte handle travels over the host-side process group -> dcfp_p2p_import), and ONE
+ * single-workgroup kernel per BatchNorm layer and direction writes this rank's row into every rank's mailbox over
+ * xGMI, waits for the others' rows in its own, and reduces them in rank order (bit-identical on all ranks).
+ *   mailboxes[r]  rank r's mailbox as mapped in THIS process (the local allocation for r == rank), world <= 16;
+ *   seq           1, 2, 3, ... - the same on all ranks for the same exchange (never 0);
+ *   cap_floats    payload capacity the mailboxes were sized for (multiple of 32); n <= cap_floats;
+ *   mode 0        out[world][n] = the rows (all-gather);
+ *   mode 1        out[n] = sum over ranks, rank order (backward: [sum g, sum g*(x-mean)] adjacent, n = 2C);
+ *   mode 2        rows = (mean[C], var[C], count), n = 2C+1: out = (pooled mean[C], pooled biased var[C], total count)
+ *                 as dcfp_syncbn_combine_f32 computes them, and `run` (nullable) is updated from the pooled values;
+ *   spin_limit    polling rounds (~0.55 us each) after which the kernel gives up: outputs = NaN, *status = seq
+ *                 (a device int32 the caller zeroed once; it is never written otherwise).
+ * dcfp_p2p_alloc kind: 0 fine-grained device memory (the default), 1 uncached, 2 plain hipMalloc; zero-filled.
+ * All ranks must have imported every mailbox before the first exchange, and unmap before the owner frees. */
+#define DCFP_P2P_HANDLE_BYTES 64
+size_t dcfp_syncbn_p2p_mailbox_bytes(int world, int cap_floats);
+int dcfp_p2p_alloc(size_t bytes, int kind, void** ptr);
+int dcfp_p2p_free(void* ptr);
+int dcfp_p2p_export(void* ptr, void* handle64);
+int dcfp_p2p_import(const void* handle64, void** ptr);
+int dcfp_p2p_unmap(void* ptr);
+int dcfp_syncbn_p2p_exchange_f32(void* const* mailboxes, int world, int rank, uint32_t seq, int cap_floats,
+                                 const float* local, int n, int mode, float* out, const DcfpBnRunning* run,
+                                 uint32_t spin_limit, int32_t* status, dcfp_stream_t stream);
 /* Running statistics of nn.BatchNorm2d in training mode (resnet.py:9, momentum 0.1):
  * running = (1-momentum)*running + momentum*stat, the variance unbiased by count/(count-1);
  * count_dev (nullable, one float) overrides `count` (SyncBN: global count on the device). */

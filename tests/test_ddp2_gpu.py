@@ -100,7 +100,8 @@ def _child(rank, world, out_path):
         state = {k: v.detach().clone() for k, v in m.state_dict().items()}
         return losses, grads, eic, state, run1, sd0
 
-    full = run(False) if rank == 0 else None
+    only = bool(os.environ.get("DCFP_DDP2_ONLY"))      # just the data-parallel run, hashed (exchange-path A/B)
+    full = run(False) if (rank == 0 and not only) else None
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=PORT, RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -114,8 +115,24 @@ def _child(rank, world, out_path):
     gboth = [torch.empty_like(gflat) for _ in range(world)]
     dist.all_gather(gboth, gflat)
     dist.barrier()
+    from dcfp_amd import syncbn_p2p
+    px = syncbn_p2p.for_group(dist.group.WORLD)
+    n_p2p = px.exchanges if px is not None else 0
+    if px is not None:
+        px.check()
+    syncbn_p2p.disable()
     dist.destroy_process_group()
     if rank != 0:
+        return
+    if only:
+        import hashlib
+        h = hashlib.sha256()
+        for t in (both[0], gboth[0]):
+            h.update(t.cpu().numpy().tobytes())
+        with open(out_path, "w") as f:
+            json.dump({"sha": h.hexdigest(), "loss_ddp": ddp[0], "p2p_exchanges": n_p2p,
+                       "ranks_state_equal": bool(torch.equal(both[0], both[1])),
+                       "ranks_grad_equal": bool(torch.equal(gboth[0], gboth[1]))}, f)
         return
 
     def rel(a, b):
@@ -147,10 +164,11 @@ def _child(rank, world, out_path):
         json.dump(out, f)
 
 
-def test_two_ranks_match_the_full_batch_and_each_other(cuda, tmp_path):
+def _run_pair(out, **env_extra):
     env = dict(os.environ)
     env.pop("DCFP_FORCE_SYNCBN", None)
-    out = str(tmp_path / "ddp2.json")
+    env.pop("DCFP_SYNCBN_P2P", None)
+    env.update(env_extra)
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "2", out], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     logs = []
@@ -163,7 +181,24 @@ def test_two_ranks_match_the_full_batch_and_each_other(cuda, tmp_path):
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d:\n%s" % (r, logs[r][-3000:])
-    rec = json.load(open(out))
+    return json.load(open(out))
+
+
+def test_p2p_syncbn_exchange_trains_bit_identically_to_the_collectives(cuda, tmp_path):
+    """Two optimizer steps of the two-rank model with the SyncBN statistics exchanged (a) by gloo collectives and
+    (b) by the peer-to-peer kernel (DCFP_SYNCBN_P2P=1; the ranks' mailboxes mapped into each other over hipIpc):
+    every weight, running statistic, EIC entry and first-step gradient must come out bit for bit the same."""
+    a = _run_pair(str(tmp_path / "a.json"), DCFP_DDP2_ONLY="1")
+    b = _run_pair(str(tmp_path / "b.json"), DCFP_DDP2_ONLY="1", DCFP_SYNCBN_P2P="1")
+    print("DDP2-P2P", json.dumps([a, b]))
+    assert a["p2p_exchanges"] == 0 and b["p2p_exchanges"] >= 2 * 2 * 50      # fwd + bwd, 2 steps, >= 50 BN layers
+    assert b["ranks_state_equal"] and b["ranks_grad_equal"]
+    assert a["sha"] == b["sha"] and a["loss_ddp"] == b["loss_ddp"]
+
+
+def test_two_ranks_match_the_full_batch_and_each_other(cuda, tmp_path):
+    out = str(tmp_path / "ddp2.json")
+    rec = _run_pair(out)
     print("DDP2", json.dumps(rec))
     assert rec["ranks_state_equal"] and rec["ranks_grad_equal"]          # bit for bit, after 2 optimizer steps
     assert abs(rec["loss_ddp"][0] - rec["loss_full"][0]) <= 2e-6 * abs(rec["loss_full"][0]), rec
