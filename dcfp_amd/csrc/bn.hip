@@ -256,6 +256,7 @@ __global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict_
 __global__ void syncbn_combine_kernel(const float* __restrict__ allv, int world, int C,
                                       float* __restrict__ gmean, float* __restrict__ gvar,
                                       float* __restrict__ total, DcfpBnRunning run) {
+#pragma clang fp contract(off)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int S = 2 * C + 1;

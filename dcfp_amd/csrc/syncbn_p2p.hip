@@ -19,10 +19,11 @@
 
 namespace {
 
-constexpr int kMaxWorld = 16;
+constexpr int kMaxWorld = 8;    // one xGMI node
 constexpr int kSlots = 4;
 constexpr int kHdr = 32;   // floats: one 128-byte line of its own in front of each payload; word 0 = seq
 constexpr int kP2pThreads = 1024;
+constexpr int kPer = 5;      // floats per lane and push pass: 5 x 1024 covers the 4097 floats of a 2048-channel layer
 
 struct Peers {
     float* box[kMaxWorld];
@@ -46,27 +47,46 @@ template <int MODE>
 __global__ void __launch_bounds__(kP2pThreads)
 syncbn_p2p_kernel(Peers peers, int world, int rank, unsigned seq, int cap, const float* __restrict__ local, int n,
                   float* __restrict__ out, DcfpBnRunning run, unsigned spin_limit, int* __restrict__ status) {
+#pragma clang fp contract(off)   // the rank-order reductions round every product and sum on their own, as the host reference does
     __shared__ int ok;
     const int tid = threadIdx.x;
     const int slot = (int)(seq % kSlots);
     if (tid == 0) ok = 1;
-    // ---- push my row to every rank (my own mailbox included: one code path, and the reduce reads one place)
-    for (int p = 0; p < world; ++p) {
-        float* e = entry_of(peers.box[p], world, cap, slot, rank) + kHdr;
-        for (int i = tid; i < n; i += kP2pThreads) st_sys(e + i, local[i]);
+    // ---- push my row to every rank (my own mailbox included: one code path, and the reduce reads one place).
+    // The row is read into registers once (kPer floats per lane and pass) and then stored to all peers back to back:
+    // no store waits for a load, the xGMI writes to the different peers are all in flight together.
+    for (int base = 0; base < n; base += kP2pThreads * kPer) {
+        float v[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = base + k * kP2pThreads + tid;
+            v[k] = i < n ? local[i] : 0.f;
+        }
+        for (int p = 0; p < world; ++p) {
+            float* e = entry_of(peers.box[p], world, cap, slot, rank) + kHdr;
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int i = base + k * kP2pThreads + tid;
+                if (i < n) st_sys(e + i, v[k]);
+            }
+        }
     }
-    __threadfence_system();
-    __syncthreads();          // every lane's stores are fenced before any flag goes out
+    // Every mailbox access of this kernel is a system-scope (sc0 sc1) access: write-through stores, cache-bypassing
+    // loads.  So "my row is visible" needs no L2 write-back (a release fence's buffer_wbl2 would flush whatever the
+    // previous conv left dirty in this XCD's L2), only that the stores have been acknowledged: vmcnt(0) in every
+    // lane, then the barrier, then the flags - which travel the same path to the same peer behind the rows.
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0) (expcnt / lgkmcnt left alone)
+    __syncthreads();
     if (tid < world) {
         unsigned* f = reinterpret_cast<unsigned*>(entry_of(peers.box[tid], world, cap, slot, rank));
-        __hip_atomic_store(f, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(f, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- pull: wait for every rank's row in my mailbox
     float* mine = peers.box[rank];
     if (tid < world) {
         const unsigned* f = reinterpret_cast<const unsigned*>(entry_of(mine, world, cap, slot, tid));
         unsigned it = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             if (++it > spin_limit) {
                 ok = 0;
                 break;
@@ -81,36 +101,61 @@ syncbn_p2p_kernel(Peers peers, int world, int rank, unsigned seq, int cap, const
         if (tid == 0) atomicExch(status, (int)seq);
         return;
     }
-    __threadfence_system();   // the payload loads below stay behind the acquire of the lanes that polled
+    // (the row loads below are system-scope loads issued after the barrier the polling lanes joined: no cached copy
+    //  can stand in for them, so no L2 invalidate is needed either)
     const float* rows = entry_of(mine, world, cap, slot, 0) + kHdr;
     const size_t rs = (size_t)(kHdr + cap);   // row r of this exchange starts at rows + r * rs
+    // Loads first, arithmetic second: a system-scope load goes to memory (~1-2 us), so the `world` loads of one output
+    // element are issued together (fixed-trip loops over kMaxWorld with r < world predicates) before any is consumed.
     if (MODE == 0) {
-        for (int r = 0; r < world; ++r)
-            for (int i = tid; i < n; i += kP2pThreads) out[(size_t)r * n + i] = ld_sys(rows + r * rs + i);
+        for (int i = tid; i < n; i += kP2pThreads) {
+            float v[kMaxWorld];
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r) v[r] = r < world ? ld_sys(rows + r * rs + i) : 0.f;
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r)
+                if (r < world) out[(size_t)r * n + i] = v[r];
+        }
     } else if (MODE == 1) {
         for (int i = tid; i < n; i += kP2pThreads) {
-            float s = ld_sys(rows + i);
-            for (int r = 1; r < world; ++r) s += ld_sys(rows + r * rs + i);
+            float v[kMaxWorld];
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r) v[r] = r < world ? ld_sys(rows + r * rs + i) : 0.f;
+            float s = v[0];
+#pragma unroll
+            for (int r = 1; r < kMaxWorld; ++r)
+                if (r < world) s += v[r];
             out[i] = s;
         }
     } else {
         // the expression of syncbn_combine_kernel (bn.hip) / ops.syncbn_combine_reference: fp64, rank order, every
         // product and sum rounded on its own
         const int C = (n - 1) / 2;
+        float cnt[kMaxWorld];
+#pragma unroll
+        for (int r = 0; r < kMaxWorld; ++r) cnt[r] = r < world ? ld_sys(rows + r * rs + 2 * C) : 0.f;
         double tot = 0.0;
-        for (int r = 0; r < world; ++r) tot = __dadd_rn(tot, (double)ld_sys(rows + r * rs + 2 * C));
+#pragma unroll
+        for (int r = 0; r < kMaxWorld; ++r)
+            if (r < world) tot = __dadd_rn(tot, (double)cnt[r]);
         for (int c = tid; c < C; c += kP2pThreads) {
+            float mr[kMaxWorld], vr[kMaxWorld];
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r) {
+                mr[r] = r < world ? ld_sys(rows + r * rs + c) : 0.f;
+                vr[r] = r < world ? ld_sys(rows + r * rs + C + c) : 0.f;
+            }
             double m = 0.0, v = 0.0;
-            for (int r = 0; r < world; ++r) {
-                const double cnt = (double)ld_sys(rows + r * rs + 2 * C);
-                m = __dadd_rn(m, __dmul_rn((double)ld_sys(rows + r * rs + c), cnt));
-            }
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r)
+                if (r < world) m = __dadd_rn(m, __dmul_rn((double)mr[r], (double)cnt[r]));
             m /= tot;
-            for (int r = 0; r < world; ++r) {
-                const double cnt = (double)ld_sys(rows + r * rs + 2 * C);
-                const double d = __dadd_rn((double)ld_sys(rows + r * rs + c), -m);
-                v = __dadd_rn(v, __dmul_rn(__dadd_rn((double)ld_sys(rows + r * rs + C + c), __dmul_rn(d, d)), cnt));
-            }
+#pragma unroll
+            for (int r = 0; r < kMaxWorld; ++r)
+                if (r < world) {
+                    const double d = __dadd_rn((double)mr[r], -m);
+                    v = __dadd_rn(v, __dmul_rn(__dadd_rn((double)vr[r], __dmul_rn(d, d)), (double)cnt[r]));
+                }
             out[c] = (float)m;
             out[C + c] = (float)(v / tot);
             running_update(run, c, (float)m, (float)(v / tot), (float)tot);

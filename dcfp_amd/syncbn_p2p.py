@@ -52,8 +52,8 @@ class SyncBnP2P:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = torch.device(device)
-        if self.world > 16:
-            raise RuntimeError("SyncBnP2P: at most 16 ranks (one node)")
+        if self.world > 8:
+            raise RuntimeError("SyncBnP2P: at most 8 ranks (one xGMI node)")
         self.cap = (2 * int(max_channels) + 1 + 31) // 32 * 32
         self.spin = int(os.environ.get("DCFP_P2P_SPIN", "200000000"))
         L = _lib.lib()

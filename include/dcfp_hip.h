@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every buffer (including workspace) is owned by the caller; the library
- *     allocates nothing and keeps no state between calls; all launches are
+ *     allocates nothing (one exception, on request: dcfp_p2p_alloc, because the SyncBN mailbox needs a fine-grained
+ *     allocation and an IPC handle torch cannot give) and keeps no state between calls; all launches are
  *     stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default).
  *     The only process-wide state is a set of tuning switches read ONCE from the
  *     environment into function-local statics on first use: DCFP_CONV_MATH (bf16x3 opt-in),
@@ -246,7 +247,7 @@ int dcfp_syncbn_combine_f32(const float* gathered, int world, int C, float* mean
  * (dcfp_p2p_export -> the 64-byte handle travels over the host-side process group -> dcfp_p2p_import), and ONE
  * single-workgroup kernel per BatchNorm layer and direction writes this rank's row into every rank's mailbox over
  * xGMI, waits for the others' rows in its own, and reduces them in rank order (bit-identical on all ranks).
- *   mailboxes[r]  rank r's mailbox as mapped in THIS process (the local allocation for r == rank), world <= 16;
+ *   mailboxes[r]  rank r's mailbox as mapped in THIS process (the local allocation for r == rank), world <= 8;
  *   seq           1, 2, 3, ... - the same on all ranks for the same exchange (never 0);
  *   cap_floats    payload capacity the mailboxes were sized for (multiple of 32); n <= cap_floats;
  *   mode 0        out[world][n] = the rows (all-gather);
