@@ -142,6 +142,10 @@ def main(argv=None):
                     torch.save(seg_model.state_dict(), osp.join(args.snapshot_dir, "CS_scenes_%d.pth" % done))
         if main_flag and train_pruning is not None:
             train_pruning.export_eic(osp.join(args.snapshot_dir, "score.pth"))
+        from dcfp_amd import syncbn_p2p
+        for px in list(syncbn_p2p._ACTIVE.values()):    # DCFP_SYNCBN_P2P=1: no exchange may have given up on a peer
+            px.check()
+        syncbn_p2p.disable()
 
 
 if __name__ == "__main__":
