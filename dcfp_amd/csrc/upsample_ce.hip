@@ -14,6 +14,7 @@
 //   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -324,6 +325,136 @@ upsample_ce_bwd_classes_kernel(const float* __restrict__ logits, const long long
 #pragma unroll
             for (int c = 0; c < CT; ++c) o[c * plane] = acc[c] * gs;
         }
+    }
+}
+
+// The same gradient organised by CELLS (19 classes, the training path).  The cell of a destination pixel is the
+// low-resolution position (i0, j0) its stencil starts at; every destination pixel lies in exactly one cell and
+// touches only that cell's four corners (i0|i1, j0|j1).  The kernel above visits every destination pixel once per
+// corner it touches - four softmax evaluations per pixel; here a lane pair owns a cell, holds the four corner
+// logit vectors in registers, evaluates each of its ~8 x 8 destination pixels ONCE and accumulates the four
+// corner sums (4 x 19 registers).  A workgroup covers a 7 x 15 tile of low-resolution outputs = 8 x 16 cells (one
+// halo row / column above and left is recomputed by the neighbour: 1.2x instead of 4x), parks the corner sums in
+// LDS and gathers, per output and class, the <= 4 (cell, corner) terms that land on it in a fixed order - no
+// atomics, deterministic.  Interpolation and softmax expressions are the forward's.
+constexpr int kCellTH = 7, kCellTW = 15, kCellThreads = 256;      // 8 x 16 cells x 2 lanes: four full waves, two
+                                                                   // workgroups per CU at 219 registers (an 8 x 16 tile
+                                                                   // with 320 threads left 3 of 8 wave slots empty)
+constexpr int kCellCount = (kCellTH + 1) * (kCellTW + 1);
+
+template <bool ALIGN, int CT>
+__global__ void __launch_bounds__(kCellThreads, 2)
+upsample_ce_bwd_cells_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                             const uint8_t* __restrict__ keep, int ignore_index, int N, int h, int w, int H,
+                             int W, float sh, float sw, const float* __restrict__ lse,
+                             const float* __restrict__ grad_scale, float* __restrict__ dlogits,
+                             const float* __restrict__ pix_weight, int scale_per_image, int tiles_w, int tiles_h) {
+    __shared__ float corner[kCellCount][4][CT + 1];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int I0 = th * kCellTH, J0 = tw * kCellTW;
+    const long long plane = (long long)h * w;
+    const float* base = logits + (long long)n * CT * plane;
+    const long long* lab = labels + (long long)n * H * W;
+    const float* ls = lse + (long long)n * H * W;
+    const uint8_t* kp = keep ? keep + (long long)n * H * W : nullptr;
+    const float* wp = pix_weight ? pix_weight + (long long)n * H * W : nullptr;
+
+    const int cell = tid >> 1, part = tid & 1;
+    if (cell < kCellCount) {
+        const int ci = I0 - 1 + cell / (kCellTW + 1), cj = J0 - 1 + cell % (kCellTW + 1);
+        float a00[CT], a01[CT], a10[CT], a11[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) a00[c] = a01[c] = a10[c] = a11[c] = 0.f;
+        if (ci >= 0 && ci < h && cj >= 0 && cj < w) {
+            const int i1 = ci + (ci < h - 1 ? 1 : 0), j1 = cj + (cj < w - 1 ? 1 : 0);
+            float p00[CT], p01[CT], p10[CT], p11[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float* p = base + c * plane;
+                p00[c] = p[ci * w + cj]; p01[c] = p[ci * w + j1];
+                p10[c] = p[i1 * w + cj]; p11[c] = p[i1 * w + j1];
+            }
+            int ylo, yhi, xlo, xhi;
+            dst_range<ALIGN>(ci, sh, H, ylo, yhi);
+            dst_range<ALIGN>(cj, sw, W, xlo, xhi);
+            for (int Y = ylo + part; Y <= yhi; Y += 2) {
+                const Lerp Lh = lerp_of<ALIGN>(Y, sh, h);
+                if (Lh.i0 != ci) continue;
+                for (int X = xlo; X <= xhi; ++X) {
+                    const Lerp Lw = lerp_of<ALIGN>(X, sw, w);
+                    if (Lw.i0 != cj) continue;
+                    const long long q = (long long)Y * W + X;
+                    const long long label = lab[q];
+                    if (label == ignore_index || (kp && !kp[q])) continue;
+                    float pw = 1.f;
+                    if (wp) {
+                        pw = wp[q];
+                        if (pw == 0.f) continue;
+                    }
+                    const float lq = ls[q];
+                    const float w00 = Lh.l0 * Lw.l0 * pw, w01 = Lh.l0 * Lw.l1 * pw;
+                    const float w10 = Lh.l1 * Lw.l0 * pw, w11 = Lh.l1 * Lw.l1 * pw;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const float z = Lh.l0 * (Lw.l0 * p00[c] + Lw.l1 * p01[c]) +
+                                        Lh.l1 * (Lw.l0 * p10[c] + Lw.l1 * p11[c]);
+                        const float g = expf(z - lq) - (label == c ? 1.f : 0.f);
+                        a00[c] += w00 * g; a01[c] += w01 * g;
+                        a10[c] += w10 * g; a11[c] += w11 * g;
+                    }
+                }
+            }
+        }
+        // the two lanes of a cell: even rows + odd rows, always in that order
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            a00[c] += __shfl_xor(a00[c], 1, 64); a01[c] += __shfl_xor(a01[c], 1, 64);
+            a10[c] += __shfl_xor(a10[c], 1, 64); a11[c] += __shfl_xor(a11[c], 1, 64);
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                corner[cell][0][c] = a00[c]; corner[cell][1][c] = a01[c];
+                corner[cell][2][c] = a10[c]; corner[cell][3][c] = a11[c];
+            }
+        }
+    }
+    __syncthreads();
+    // gather: output (i, j) collects corner (a, b) of cell (ci, cj) wherever ci + (a && ci < h-1) == i and
+    // cj + (b && cj < w-1) == j; candidates are ci in {i-1, i}, cj in {j-1, j}; fixed visiting order
+    const float gs = grad_scale[scale_per_image ? n : 0];
+    for (int o = tid; o < kCellTH * kCellTW * CT; o += kCellThreads) {
+        const int c = o / (kCellTH * kCellTW);
+        const int r = o - c * (kCellTH * kCellTW);
+        const int li = r / kCellTW, lj = r - li * kCellTW;
+        const int i = I0 + li, j = J0 + lj;
+        if (i >= h || j >= w) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+            const int ci = i - 1 + di;
+            if (ci < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (ci + ((a && ci < h - 1) ? 1 : 0) != i) continue;
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    const int cj = j - 1 + dj;
+                    if (cj < 0) continue;
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        if (cj + ((bb && cj < w - 1) ? 1 : 0) != j) continue;
+                        acc += corner[(li + di) * (kCellTW + 1) + (lj + dj)][a * 2 + bb][c];
+                    }
+                }
+            }
+        }
+        dlogits[((long long)n * CT + c) * plane + (long long)i * w + j] = acc * gs;
     }
 }
 
@@ -671,6 +802,25 @@ extern "C" int dcfp_upsample_ce_fwd_f32(const float* logits, const int64_t* labe
     DCFP_RETURN_LAUNCH();
 }
 
+// 19-class backward: the cell-organised kernel (DCFP_CE_BWD_CELLS=0: the per-output kernel, for A/B)
+template <bool ALIGN>
+static void launch_ce_bwd_19(const float* logits, const long long* lab, const uint8_t* keep, int ignore_index, int N,
+                             int h, int w, int H, int W, float sh, float sw, const float* lse, const float* gscale,
+                             float* dlogits, const float* pix_weight, int per_image, hipStream_t st) {
+    static const bool cells = [] { const char* e = getenv("DCFP_CE_BWD_CELLS"); return !e || atoi(e) != 0; }();
+    if (cells) {
+        const int tiles_w = (w + kCellTW - 1) / kCellTW, tiles_h = (h + kCellTH - 1) / kCellTH;
+        hipLaunchKernelGGL((upsample_ce_bwd_cells_kernel<ALIGN, 19>), dim3((unsigned)(N * tiles_h * tiles_w)),
+                           dim3(kCellThreads), 0, st, logits, lab, keep, ignore_index, N, h, w, H, W, sh, sw, lse,
+                           gscale, dlogits, pix_weight, per_image, tiles_w, tiles_h);
+        return;
+    }
+    const long long tot2 = (long long)N * h * w * 4;   // 4 lanes per low-resolution pixel
+    const unsigned b2 = (unsigned)((tot2 + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<ALIGN, 19>), dim3(b2), dim3(kThreads), 0, st, logits, lab,
+                       keep, ignore_index, N, h, w, H, W, sh, sw, lse, gscale, dlogits, pix_weight, per_image);
+}
+
 extern "C" int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labels,
                                         const uint8_t* pixel_keep, int ignore_index, int N, int C,
                                         int h, int w, int H, int W, int align_corners,
@@ -684,17 +834,14 @@ extern "C" int dcfp_upsample_ce_bwd_f32(const float* logits, const int64_t* labe
     const long long* lab = reinterpret_cast<const long long*>(labels);
     long long blocks = (total + kThreads - 1) / kThreads;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
-    if (C == 19) {   // Cityscapes (datasets/CSdatasets.py:13): class-batched variant
-        const long long tot2 = (long long)N * h * w * 4;   // 4 lanes per low-resolution pixel
-        const unsigned b2 = (unsigned)((tot2 + kThreads - 1) / kThreads);
+    if (C == 19 && (long long)N * ((h + kCellTH - 1) / kCellTH) * ((w + kCellTW - 1) / kCellTW) <= 0x7fffffffLL) {
+        // Cityscapes (datasets/CSdatasets.py:13): all classes in registers
         if (align_corners)
-            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<true, 19>), dim3(b2), dim3(kThreads), 0,
-                               dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw,
-                               lse, grad_scale, dlogits, nullptr, 0);
+            launch_ce_bwd_19<true>(logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw, lse, grad_scale,
+                                   dlogits, nullptr, 0, dcfp_s(stream));
         else
-            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<false, 19>), dim3(b2), dim3(kThreads), 0,
-                               dcfp_s(stream), logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw,
-                               lse, grad_scale, dlogits, nullptr, 0);
+            launch_ce_bwd_19<false>(logits, lab, pixel_keep, ignore_index, N, h, w, H, W, sh, sw, lse, grad_scale,
+                                    dlogits, nullptr, 0, dcfp_s(stream));
         DCFP_RETURN_LAUNCH();
     }
     if (align_corners)
@@ -796,17 +943,13 @@ extern "C" int dcfp_upsample_wce_bwd_f32(const float* logits, const int64_t* lab
     const long long* lab = reinterpret_cast<const long long*>(labels);
     long long blocks = (total + kThreads - 1) / kThreads;
     if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
-    if (C == 19) {   // class-batched variant (see upsample_ce_bwd_classes_kernel)
-        const long long tot2 = (long long)N * h * w * 4;
-        const unsigned b2 = (unsigned)((tot2 + kThreads - 1) / kThreads);
+    if (C == 19) {   // all classes in registers (see upsample_ce_bwd_cells_kernel)
         if (align_corners)
-            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<true, 19>), dim3(b2), dim3(kThreads), 0,
-                               dcfp_s(stream), logits, lab, nullptr, ignore_index, N, h, w, H, W, sh, sw, lse,
-                               grad_scale_per_image, dlogits, pix_weight, 1);
+            launch_ce_bwd_19<true>(logits, lab, nullptr, ignore_index, N, h, w, H, W, sh, sw, lse,
+                                   grad_scale_per_image, dlogits, pix_weight, 1, dcfp_s(stream));
         else
-            hipLaunchKernelGGL((upsample_ce_bwd_classes_kernel<false, 19>), dim3(b2), dim3(kThreads), 0,
-                               dcfp_s(stream), logits, lab, nullptr, ignore_index, N, h, w, H, W, sh, sw, lse,
-                               grad_scale_per_image, dlogits, pix_weight, 1);
+            launch_ce_bwd_19<false>(logits, lab, nullptr, ignore_index, N, h, w, H, W, sh, sw, lse,
+                                    grad_scale_per_image, dlogits, pix_weight, 1, dcfp_s(stream));
         DCFP_RETURN_LAUNCH();
     }
     if (align_corners)
