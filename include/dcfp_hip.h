@@ -16,7 +16,8 @@
  *     DCFP_CONV_WINOGRAD (0 direct kernels only / 1 cost model, default / 2 wherever eligible),
  *     DCFP_IGEMM_{DMA,DMA9,DMA8,2D,BK32,PERSIST,P128,TAPSKIP}, DCFP_WGRAD_{DMA,DMA_MIXED,WIDE,LOPSIDED,T192},
  *     DCFP_WINO_VEC, DCFP_WINO_FUSED (0 three-pass Winograd only / 1 fused kernel where it wins, default / 2 wherever it
- *     applies), DCFP_WF_SCALAR_EPI, DCFP_CONV_GEMV (0: 1x1 convs on a 1 x 1 map through the general kernels) -
+ *     applies), DCFP_WF_SCALAR_EPI, DCFP_CONV_GEMV (0: 1x1 convs on a 1 x 1 map through the general kernels),
+ *     DCFP_CE_BWD_CELLS (0: the per-output fused upsample + CE backward instead of the cell-organised one) -
  *     kernel / algorithm selection A/B knobs, results are identical up to the documented
  *     fp32 tolerances; changing them after the first call has no effect.  (A thread_local 16-entry cache
  *     of dispatch decisions for dilated convs is the only other state.)
