@@ -1,4 +1,4 @@
-"""The peer-to-peer SyncBatchNorm exchange (dcfp_amd/csrc/syncbn_p2p.hip, dcfp_amd/syncbn_p2p.py) with TWO real
+"""The peer-to-peer SyncBatchNorm exchange (dcfp_amd/csrc/syncbn_p2p.hip, dcfp_amd/syncbn_p2p.py) with TWO (and FOUR) real
 processes on one MI355X: each rank's mailbox is mapped into the other through hipIpc, exactly as across GPUs
 (engine.py:65 of the reference: nn.SyncBatchNorm's per-layer all_gather / all_reduce).  Checked against what the
 gloo collectives deliver for the same rows: gather bit-exact, rank-order sum bit-exact, the pooled statistics
@@ -28,7 +28,7 @@ def _child(rank, world, out_path):
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=PORT, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(PORT) + world), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     g = dist.group.WORLD
@@ -90,7 +90,7 @@ def _child(rank, world, out_path):
     outs, wants = [], []
     base = torch.arange(2 * Cc, device=dev, dtype=torch.float32)
     for k in range(400):
-        if k % 50 == (7 if rank == 0 else 31):
+        if k % 50 == 7 + 11 * rank:
             time.sleep(0.05)
         local = base * float(rank + 1) + float(k)
         out = torch.empty(2 * Cc, device=dev)
@@ -131,12 +131,14 @@ def _child(rank, world, out_path):
         json.dump(rec, f)
 
 
-def test_p2p_exchange_two_processes_one_gpu(cuda, tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchange_processes_sharing_one_gpu(cuda, tmp_path, world):
+    """world = 4: four mailboxes mapped into each other, four-term rank-order sums (the box allows 6 GPU processes)."""
     out = str(tmp_path / "p2p.json")
     env = dict(os.environ)
     env.pop("DCFP_SYNCBN_P2P", None)
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "2", out], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), str(world), out], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     try:
         for p in procs:
@@ -147,10 +149,10 @@ def test_p2p_exchange_two_processes_one_gpu(cuda, tmp_path):
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d:\n%s" % (r, logs[r][-3000:])
-    recs = [json.load(open(out + ".%d" % r)) for r in range(2)]
+    recs = [json.load(open(out + ".%d" % r)) for r in range(world)]
     print("P2P", json.dumps(recs))
     for rec in recs:
-        assert rec["world"] == 2 and rec["basic_ok"] and rec["stress_ok"], rec
+        assert rec["world"] == world and rec["basic_ok"] and rec["stress_ok"], rec
         assert rec["exchanges"] == 4 * 3 + 400
     assert recs[0]["timeout_nan"] and recs[0]["timeout_raised"] and recs[0]["timeout_s"] < 30.0, recs[0]
 
