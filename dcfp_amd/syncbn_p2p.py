@@ -60,27 +60,50 @@ class SyncBnP2P:
         nbytes = L.dcfp_syncbn_p2p_mailbox_bytes(self.world, self.cap)
         if nbytes == 0:
             raise RuntimeError("SyncBnP2P: bad mailbox geometry")
+        # Set-up fails on ALL ranks or on none: every rank reaches both object all-gathers whatever happened to it
+        # locally, and the verdict is the AND of everybody's (a rank raising alone would leave the others in a barrier).
+        self.local, self._mapped, err, raw = None, [], None, None
+        self.boxes = (C.c_void_p * self.world)()
         with torch.cuda.device(self.device):
-            self.local = C.c_void_p()
-            _lib.check(L.dcfp_p2p_alloc(nbytes, int(os.environ.get("DCFP_P2P_MEM", "0")), C.byref(self.local)),
-                       "p2p_alloc")
-            handle = C.create_string_buffer(64)
-            _lib.check(L.dcfp_p2p_export(self.local, handle), "p2p_export (hipIpcGetMemHandle)")
-            rows = [None] * self.world
-            dist.all_gather_object(rows, (handle.raw, os.getpid()), group=group)
-            self.boxes = (C.c_void_p * self.world)()
-            self._mapped = []
-            for r, (raw, pid) in enumerate(rows):
-                if r == self.rank:
-                    self.boxes[r] = self.local
-                    continue
-                if pid == os.getpid():
-                    raise RuntimeError("SyncBnP2P: two ranks in one process")
+            try:
                 ptr = C.c_void_p()
-                _lib.check(L.dcfp_p2p_import(C.create_string_buffer(raw, 64), C.byref(ptr)),
-                           "p2p_import (hipIpcOpenMemHandle) of rank %d" % r)
-                self.boxes[r] = ptr
-                self._mapped.append(ptr)
+                _lib.check(L.dcfp_p2p_alloc(nbytes, int(os.environ.get("DCFP_P2P_MEM", "0")), C.byref(ptr)), "p2p_alloc")
+                self.local = ptr
+                handle = C.create_string_buffer(64)
+                _lib.check(L.dcfp_p2p_export(self.local, handle), "p2p_export (hipIpcGetMemHandle)")
+                raw = handle.raw
+            except Exception as e:       # noqa: BLE001 - reported through the all-gather below
+                err = "rank %d: %s" % (self.rank, e)
+            rows = [None] * self.world
+            dist.all_gather_object(rows, (raw, os.getpid(), err), group=group)
+            if err is None and all(r[2] is None for r in rows):
+                try:
+                    for r, (peer_raw, pid, _) in enumerate(rows):
+                        if r == self.rank:
+                            self.boxes[r] = self.local
+                            continue
+                        if pid == os.getpid():
+                            raise RuntimeError("two ranks in one process")
+                        ptr = C.c_void_p()
+                        _lib.check(L.dcfp_p2p_import(C.create_string_buffer(peer_raw, 64), C.byref(ptr)),
+                                   "p2p_import (hipIpcOpenMemHandle) of rank %d" % r)
+                        self.boxes[r] = ptr
+                        self._mapped.append(ptr)
+                except Exception as e:   # noqa: BLE001
+                    err = "rank %d: %s" % (self.rank, e)
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err if err is not None else next((r[2] for r in rows if r[2]), None),
+                                   group=group)
+            bad = [e for e in errs if e]
+            if bad:
+                for ptr in self._mapped:
+                    L.dcfp_p2p_unmap(ptr)
+                self._mapped = []
+                dist.barrier(group=group)      # everyone has unmapped before anyone frees
+                if self.local is not None:
+                    L.dcfp_p2p_free(self.local)
+                    self.local = None
+                raise RuntimeError("SyncBnP2P set-up failed (%s)" % "; ".join(sorted(set(bad))))
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
         self.exchanges = 0

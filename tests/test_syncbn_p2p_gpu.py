@@ -32,6 +32,19 @@ def _child(rank, world, out_path):
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     g = dist.group.WORLD
+    if os.environ.get("P2P_TEST_SETUP_FAILURE"):      # ONE rank cannot allocate: every rank must raise, none may hang
+        if rank == 1:
+            os.environ["DCFP_P2P_MEM"] = "9"
+        try:
+            syncbn_p2p.enable(g, dev)
+            raised = None
+        except RuntimeError as e:
+            raised = str(e)
+        dist.barrier()
+        dist.destroy_process_group()
+        with open(out_path + ".%d" % rank, "w") as f:
+            json.dump({"raised": raised}, f)
+        return
     px = syncbn_p2p.enable(g, dev, max_channels=2048)
     rec = {"world": px.world, "cap": px.cap}
 
@@ -155,6 +168,26 @@ def test_p2p_exchange_processes_sharing_one_gpu(cuda, tmp_path, world):
         assert rec["world"] == world and rec["basic_ok"] and rec["stress_ok"], rec
         assert rec["exchanges"] == 4 * 3 + 400
     assert recs[0]["timeout_nan"] and recs[0]["timeout_raised"] and recs[0]["timeout_s"] < 30.0, recs[0]
+
+
+def test_p2p_setup_failure_on_one_rank_raises_on_all(cuda, tmp_path):
+    out = str(tmp_path / "p2pf.json")
+    env = dict(os.environ, P2P_TEST_SETUP_FAILURE="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "2", out], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=200)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, logs[r][-3000:])
+    recs = [json.load(open(out + ".%d" % r)) for r in range(2)]
+    for rec in recs:
+        assert rec["raised"] and "rank 1" in rec["raised"] and "p2p_alloc" in rec["raised"], recs
 
 
 if __name__ == "__main__" and "--child" in sys.argv:
