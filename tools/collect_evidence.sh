@@ -10,6 +10,7 @@ timeout -k 10 400 python bench.py --steps 8 --warmup 3 > $out/${tag}_final_bench
 find $out/${tag}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_final_bench_n1_kernel_stats.csv
 rm -rf $out/${tag}_prof
 timeout -k 10 300 python bench.py --steps 6 --warmup 3 --force-ddp --no-cpu-baseline > $out/${tag}_bench_ddp_ws1.json 2> $out/${tag}_bench_ddp_ws1.err || echo "ddp rehearsal failed"
+timeout -k 10 300 python bench.py --steps 6 --warmup 3 --force-ddp --syncbn-p2p --no-cpu-baseline > $out/${tag}_bench_ddp_ws1_p2p.json 2> $out/${tag}_bench_ddp_ws1_p2p.err || echo "ddp p2p rehearsal failed"
 timeout -k 10 300 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --channel-cfg tools/data/channel_cfg_r101_p60_synthetic.pth > $out/${tag}_bench_pruned_cfg5.json 2> $out/${tag}_bench_pruned.err || echo "pruned bench failed"
 for F in 0 1; do echo "DCFP_WINO_FUSED=$F"; DCFP_WINO_FUSED=$F timeout -k 10 250 python tools/micro/wino_fused_variants.py l3c2_3x3d2,l4c2_3x3d4,l4c2_3x3d16,aspp_3x3d12,aspp_3x3d24,ds_3x3 2>&1 | grep -v "MIOpen\|amdgpu.ids"; done > $out/${tag}_wino_fused_ab.txt 2>&1
 bash tools/prof_traffic.sh $out/${tag}_traffic tools/conv_bench.py --shapes l3c2_3x3d2 --passes fwd,dgrad --pitched --iters 4 > /dev/null 2>&1
