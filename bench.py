@@ -149,12 +149,12 @@ def roofline_from_profile(recs, images_per_step, step_s):
     # process): corrected FETCH_SIZE + WRITE_SIZE of the same kernel instance on its dominant shape
     traffic = traffic_note = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_conv_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_conv_traffic.json")) as f:
             tk = json.load(f)["kernels"].get(dom)
         if tk:
             traffic = tk["fetch_bytes_corrected"] + tk["write_bytes"]
             traffic_note = ("bytes/launch beyond L2 (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, "
-                            "profiles/r02_conv_traffic_pmc.txt): " + tk["note"] +
+                            "profiles/r03_conv_traffic_pmc.txt): " + tk["note"] +
                             f"; algorithmic bytes of that launch {tk['algorithmic_bytes'] / 1e6:.0f} MB")
     except Exception:
         pass
