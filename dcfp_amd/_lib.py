@@ -66,6 +66,9 @@ SIGNATURES = {
     "dcfp_conv2d_workspace_is_scratch": (_I, [_D, _I]),
     "dcfp_conv2d_dgrad_fanin_supported": (_I, [_D]),
     "dcfp_conv2d_dgrad_fanin_f32_nchw": (_I, [_D, _P, _L, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "dcfp_conv2d_dgrad_fanin_red_slots": (_L, [_D]),
+    "dcfp_conv2d_dgrad_fanin_red_f32_nchw": (_I, [_D, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "dcfp_bn_bwd_sums_from_partials_f32": (_I, [_P, _L, _I, _P, _F, _P, _P, _P, _P, _P]),
     "dcfp_conv2d_xform_bytes": (_Z, [_D]),
     "dcfp_conv2d_fwd_keep_f32_nchw": (_I, [_D, _P, _P, _P, _L, _P, _Z, _P, _P, _Z, _P]),
     "dcfp_conv2d_wgrad_kept_f32_nchw": (_I, [_D, _P, _L, _P, _Z, _P, _P, _Z, _P]),

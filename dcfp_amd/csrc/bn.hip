@@ -357,6 +357,49 @@ bn_stats_from_partials_kernel(const float* __restrict__ part, long long S, int c
     }
 }
 
+// BatchNorm-backward sums from the fan-in dgrad's side output (igemm2_dma1p_kernel<..., RED>): part[s][c] = (sum g,
+// sum g*(x - mean)) over 128 pixels each -> S1[c], S2[c] in fp64, slots in a fixed order (thread (g, l) takes the
+// slots s = g, g + groups, ...; the groups' sums are added in order), then what bn_pair_final_kernel writes.
+__global__ void __launch_bounds__(kSfpThreads)
+bn_bwd_sums_from_partials_kernel(const float* __restrict__ part, long long S, int C, const float* __restrict__ var,
+                                 float eps, float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3,
+                                 float* __restrict__ o4) {
+    constexpr int kCh = 32, kGroups = kSfpThreads / kCh;
+    __shared__ double r1[kGroups][kCh], r2[kGroups][kCh];
+    const int l = threadIdx.x % kCh, g = threadIdx.x / kCh;
+    const int c = blockIdx.x * kCh + l;
+    const bool on = c < C;
+    const float2* p2 = reinterpret_cast<const float2*>(part);
+    constexpr int U = 4;
+    double a[U] = {0.0, 0.0, 0.0, 0.0}, b[U] = {0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        long long s = g;
+        for (; s + (U - 1) * kGroups < S; s += U * kGroups) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = p2[(s + u * kGroups) * C + c];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] += (double)v[u].x; b[u] += (double)v[u].y; }
+        }
+        for (; s < S; s += kGroups) {
+            const float2 v = p2[s * C + c];
+            a[0] += (double)v.x; b[0] += (double)v.y;
+        }
+    }
+    r1[g][l] = (a[0] + a[1]) + (a[2] + a[3]);
+    r2[g][l] = (b[0] + b[1]) + (b[2] + b[3]);
+    __syncthreads();
+    if (g == 0 && on) {
+        double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kGroups; ++k) { S1 += r1[k][l]; S2 += r2[k][l]; }
+        o1[c] = (float)S1;
+        o2[c] = (float)S2;
+        if (o3) o3[c] = (float)S2 * rsqrtf(var[c] + eps);
+        if (o4) o4[c] = (float)S1;
+    }
+}
+
 // running = (1-m)*running + m*stat, variance unbiased by count/(count-1) (nn.BatchNorm2d training)
 __global__ void bn_running_kernel(int C, const float* __restrict__ mean, const float* __restrict__ var,
                                   float momentum, float count, const float* __restrict__ count_dev,
@@ -631,5 +674,15 @@ extern "C" int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t sl
     else
         hipLaunchKernelGGL(bn_stats_from_partials_kernel<32>, dim3((unsigned)((C + 31) / 32)), dim3(kSfpThreads), 0,
                            dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
+    DCFP_RETURN_LAUNCH();
+}
+
+extern "C" int dcfp_bn_bwd_sums_from_partials_f32(const float* partials, int64_t slots, int C, const float* var, float eps,
+                                                  float* sum_dy, float* sum_dy_xmu, float* dgamma, float* dbeta,
+                                                  dcfp_stream_t stream) {
+    if (!partials || slots <= 0 || C <= 0 || !sum_dy || !sum_dy_xmu || (dgamma && !var)) return DCFP_E_BADDESC;
+    if (reinterpret_cast<uintptr_t>(partials) & 7u) return DCFP_E_BADDESC;
+    hipLaunchKernelGGL(bn_bwd_sums_from_partials_kernel, dim3((unsigned)((C + 31) / 32)), dim3(kSfpThreads), 0,
+                       dcfp_s(stream), partials, (long long)slots, C, var, eps, sum_dy, sum_dy_xmu, dgamma, dbeta);
     DCFP_RETURN_LAUNCH();
 }

@@ -14,6 +14,14 @@
         return (e__ == hipSuccess) ? DCFP_OK : (int)e__; \
     } while (0)
 
+// the BatchNorm-backward-sums side output of the fan-in dgrad (Igemm2Params::red_*), as dcfp_igemm2_run takes it
+struct Igemm2Red {
+    const float* x;
+    const unsigned long long* mask;
+    const float* mean;
+    float* part;
+};
+
 static inline hipStream_t dcfp_s(dcfp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline bool dcfp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

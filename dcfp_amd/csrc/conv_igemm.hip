@@ -56,7 +56,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     const float* scale = nullptr, const float* shift = nullptr,
                     const float* residual = nullptr, int relu = 0, float* stat_part = nullptr, int wp_valid = 0,
                     int in_pitch = 0, long long wp_nstride = 0, const float* fan_src = nullptr,
-                    const unsigned long long* fan_mask = nullptr);
+                    const unsigned long long* fan_mask = nullptr, const Igemm2Red* red = nullptr);
 // conv_winograd.hip
 bool dcfp_wino_ok(int N, int H, int W, int d, int M, int Ck);
 size_t dcfp_wino_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
@@ -376,6 +376,39 @@ extern "C" int dcfp_conv2d_dgrad_fanin_f32_nchw(const DcfpConvDesc* d, const flo
                            (long long)d->Cin * d->H * d->W, d->N, d->Cin, d->Cout, 1, d->Hout, d->Wout, d->H, d->W, 1, 1, 0, -1,
                            0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0, nullptr, wp_valid, 0, 0,
                            fan_src, static_cast<const unsigned long long*>(fan_mask));
+}
+
+// The fan-in with the PREVIOUS residual block's BatchNorm-backward sums as a side output: dx (this call's result) is the
+// gradient arriving at that block's output; with its bn3 input `red_x`, its ReLU bit mask `red_mask` and batch mean
+// `red_mean` the epilogue emits red_part[slot][Cin][2] = (sum g, sum g*(x - mean)) per 128 pixels, g = dx * mask -
+// dcfp_bn_bwd_sums_from_partials_f32 turns them into what dcfp_bn_bwd_reduce_f32 returns, and that block's backward skips
+// its reduce kernel (which would re-read dx and x: 8 B/element).  dcfp_conv2d_dgrad_fanin_red_slots: the slot count
+// (N*H*W/128) where this form exists (fan-in supported and the launch takes 128-row tiles), else 0.
+bool dcfp_igemm2p_fan_red_ok(int Mpad, int CkP);
+int dcfp_igemm2_ck_pad();
+extern "C" int64_t dcfp_conv2d_dgrad_fanin_red_slots(const DcfpConvDesc* d) {
+    if (!dcfp_conv2d_dgrad_fanin_supported(d)) return 0;
+    const int pad = dcfp_igemm2_ck_pad();
+    const int ckp = (d->Cout + pad - 1) / pad * pad;
+    if (!dcfp_igemm2p_fan_red_ok(d->Cin, ckp)) return 0;
+    return (int64_t)d->N * d->H * d->W / 128;
+}
+
+extern "C" int dcfp_conv2d_dgrad_fanin_red_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride,
+                                                    const float* w, float* dx, const float* fan_src, const void* fan_mask,
+                                                    const float* red_x, const void* red_mask, const float* red_mean,
+                                                    float* red_part, void* workspace, size_t workspace_bytes, int wp_valid,
+                                                    dcfp_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !w || !dx || !fan_src || !fan_mask || !red_x || !red_mask || !red_mean || !red_part) return DCFP_E_BADDESC;
+    if (dcfp_conv2d_dgrad_fanin_red_slots(d) <= 0) return DCFP_E_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(red_part) & 7u) return DCFP_E_BADDESC;
+    const Igemm2Red red = {red_x, static_cast<const unsigned long long*>(red_mask), red_mean, red_part};
+    return dcfp_igemm2_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w, 1, d->Cin, nullptr, dx,
+                           (long long)d->Cin * d->H * d->W, d->N, d->Cin, d->Cout, 1, d->Hout, d->Wout, d->H, d->W, 1, 1, 0, -1,
+                           0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr, nullptr, 0, nullptr, wp_valid, 0, 0,
+                           fan_src, static_cast<const unsigned long long*>(fan_mask), &red);
 }
 
 // Inference: conv + folded eval-mode BatchNorm (+residual) (+ReLU) in the conv epilogue.

@@ -1154,13 +1154,16 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale, const float* shift, const float* residual, int relu,
                     float* stat_part, int wp_valid, int in_pitch, long long wp_nstride, const float* fan_src,
-                    const unsigned long long* fan_mask) {
+                    const unsigned long long* fan_mask, const Igemm2Red* red) {
     const long long px = (long long)N * Ho * Wo;
     const TileCfg c = pick_cfg(M, px, sd);
     Igemm2Params p;
     p.stat_part = stat_part;
     p.wp_nstride = wp_nstride;
     p.fan_src = fan_src; p.fan_mask = fan_mask;
+    p.red_x = red ? red->x : nullptr; p.red_mask = red ? red->mask : nullptr;
+    p.red_mean = red ? red->mean : nullptr; p.red_part = red ? red->part : nullptr;
+    if (red && !fan_src) return DCFP_E_BADDESC;
     p.in = in; p.bias = bias; p.out = out;
     p.scale = scale; p.shift = shift; p.residual = residual; p.relu = relu;
     p.in_nstride = in_nstride; p.out_nstride = out_nstride;

@@ -50,7 +50,9 @@ constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, 
 // stores and barrier waits overlap the other's MFMAs (the K = 256 layers, whose 256 x 256 tiles are store-bound).
 // FAN: out = result + (mask bit ? fan_src : 0) - the block-input gradient of a Bottleneck without materialising the
 // residual branch's gradient (dy * ReLU mask): the BatchNorm backward then skips that 4 B/element write
-template <bool ACC, bool WPI = false, int TM_ = 4, bool FAN = false>
+// RED (with FAN): the epilogue also emits the BatchNorm-backward sums of the residual block whose output gradient this
+// fan-in produces (Igemm2Params::red_*): per output row and 128-pixel slot, reduced over the 32 lanes of a row by DPP
+template <bool ACC, bool WPI = false, int TM_ = 4, bool FAN = false, bool RED = false>
 __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(const Igemm2Params p, int total_tiles, int dbg) {
     constexpr int TM = TM_, TN = 4, WN = 2, BM = 64 * TM_, BN = 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -297,12 +299,45 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
                 const unsigned long long* mrow = p.fan_mask +
                     ((long long)img * p.M + m0 + wm * (TM * 32) + TM * 4 * lhi) * words + 4 * (p0 >> 8);
                 const int bit = wn * 32 + l31;
+                // RED operands: same tile geometry as the output
+                const long long row0 = (long long)m0 + wm * (TM * 32) + TM * 4 * lhi;      // this lane's first output row
+                __amdgpu_buffer_rsrc_t x_rsrc = o_rsrc;
+                const unsigned long long* xrow = nullptr;
+                const float* mu_row = nullptr;
+                float* rp = nullptr;
+                if constexpr (RED) {
+                    x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(p.red_x) + (long long)img * p.out_nstride + (long long)m0 * p.P + p0, 0, 0x7ffffffcu,
+                        0x00020000);
+                    xrow = p.red_mask + ((long long)img * p.M + row0) * words + 4 * (p0 >> 8);
+                    mu_row = p.red_mean + row0;
+                    rp = p.red_part + ((long long)(nt * WN + wn) * p.M + row0) * 2;
+                }
+                // sum over the 32 lanes that share an output row (lanes 0..31 / 32..63): three DPP steps inside the rows of
+                // 16, row_bcast15 into the odd rows, readlane 31 / 63
+                auto red32 = [&](float v) -> float {
+                    auto dpp = [](float x, auto ctrl_) {
+                        constexpr int ctrl = decltype(ctrl_)::value;
+                        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true));
+                    };
+                    v += dpp(v, std::integral_constant<int, 0xB1>{});        // quad_perm [1,0,3,2]
+                    v += dpp(v, std::integral_constant<int, 0x4E>{});        // quad_perm [2,3,0,1]
+                    v += dpp(v, std::integral_constant<int, 0x141>{});       // row_half_mirror
+                    v += dpp(v, std::integral_constant<int, 0x140>{});       // row_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+                    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+                    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+                    return lhi ? hi : lo;
+                };
                 static_for<0, TM>([&](auto i_) {
                     constexpr int i = decltype(i_)::value;
                     static_for<0, 4>([&](auto g_) {          // four rows at a time (registers)
                         constexpr int g4 = decltype(g_)::value;
                         f32x4 src[4];
                         u64x2 ma[4], mb[4];
+                        f32x4 xs[4];
+                        u64x2 xa[4], xb[4];
+                        float mu[4];
                         static_for<0, 4>([&](auto q_) {
                             constexpr int r = 4 * g4 + decltype(q_)::value;
                             constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
@@ -310,6 +345,13 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
                                 f_rsrc, voff, (unsigned)row * P4, 0));
                             const u64x2* mq = reinterpret_cast<const u64x2*>(mrow + (long long)row * words);
                             ma[r & 3] = mq[0]; mb[r & 3] = mq[1];
+                            if constexpr (RED) {
+                                xs[r & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    x_rsrc, voff, (unsigned)row * P4, 0));
+                                const u64x2* xq = reinterpret_cast<const u64x2*>(xrow + (long long)row * words);
+                                xa[r & 3] = xq[0]; xb[r & 3] = xq[1];
+                                mu[r & 3] = mu_row[row];
+                            }
                         });
                         static_for<0, 4>([&](auto q_) {
                             constexpr int r = 4 * g4 + decltype(q_)::value;
@@ -323,6 +365,22 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
                                 __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
                                 o_rsrc, voff + (unsigned)row * P4, 0, 0);
+                            if constexpr (RED) {
+                                const float g0 = ((xa[r & 3][0] >> bit) & 1ull) ? v[0] : 0.f;
+                                const float g1 = ((xa[r & 3][1] >> bit) & 1ull) ? v[1] : 0.f;
+                                const float g2 = ((xb[r & 3][0] >> bit) & 1ull) ? v[2] : 0.f;
+                                const float g3 = ((xb[r & 3][1] >> bit) & 1ull) ? v[3] : 0.f;
+                                const f32x4 x4 = xs[r & 3];
+                                const float m_ = mu[r & 3];
+                                const float s1 = red32((g0 + g1) + (g2 + g3));
+                                const float s2 = red32((g0 * (x4[0] - m_) + g1 * (x4[1] - m_)) +
+                                                       (g2 * (x4[2] - m_) + g3 * (x4[3] - m_)));
+                                if (l31 == 0) {
+                                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                    const f32x2 pr = {s1, s2};
+                                    *reinterpret_cast<f32x2*>(rp + row * 2) = pr;
+                                }
+                            }
                         });
                         __builtin_amdgcn_sched_barrier(0);
                     });
@@ -358,6 +416,16 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
 
 }  // namespace
 
+// 128-row tiles, two workgroups per CU: DCFP_IGEMM_P128 = 0 off, 1 the K <= 256 problems (default), 2 all
+static int p128_mode() {
+    static const int p128 = [] { const char* e = getenv("DCFP_IGEMM_P128"); return e ? atoi(e) : 1; }();
+    return p128;
+}
+// the fan-in launch of (Mpad, CkP) takes the 128-row tiles - the only ones with the BatchNorm-sums side output
+bool dcfp_igemm2p_fan_red_ok(int Mpad, int CkP) {
+    return Mpad % 256 == 0 && (p128_mode() == 2 || (p128_mode() == 1 && CkP <= 256));
+}
+
 // Launch over all tiles of the problem described by `p` (filled by dcfp_igemm2_run).  One workgroup per CU.
 int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
     static int cus = 0;
@@ -369,8 +437,7 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
         else
             cus = 256;
     }
-    // 128-row tiles, two workgroups per CU: DCFP_IGEMM_P128 = 0 off, 1 the K <= 256 problems (default), 2 all
-    static const int p128 = [] { const char* e = getenv("DCFP_IGEMM_P128"); return e ? atoi(e) : 1; }();
+    const int p128 = p128_mode();
     const bool half = !p.stat_part && p.Mpad % 256 == 0 && (p128 == 2 || (p128 == 1 && p.CkP <= 256));
     Igemm2Params q = p;
     if (half) q.tiles_m = p.tiles_m * 2;
@@ -400,6 +467,11 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
     }
     if (p.fan_src) {      // interior tiles only (checked by the caller: M % 256 == 0, P % 256 == 0)
         if (p.accumulate || p.stat_part || !p.fan_mask) return DCFP_E_UNSUPPORTED;
+        if (p.red_part) {
+            if (!p.red_x || !p.red_mask || !p.red_mean) return DCFP_E_BADDESC;
+            if (!half) return DCFP_E_UNSUPPORTED;      // (the 256-row instance would spill: dcfp_igemm2p_fan_red_ok)
+            return launch(igemm2_dma1p_kernel<false, false, 2, true, true>);
+        }
         return half ? launch(igemm2_dma1p_kernel<false, false, 2, true>) : launch(igemm2_dma1p_kernel<false, false, 4, true>);
     }
     if (half) return p.accumulate ? launch(igemm2_dma1p_kernel<true, false, 2>) : launch(igemm2_dma1p_kernel<false, false, 2>);

@@ -24,7 +24,7 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
                     const float* scale, const float* shift, const float* residual, int relu, float* stat_part,
                     int wp_valid, int in_pitch, long long wp_nstride, const float* fan_src = nullptr,
-                    const unsigned long long* fan_mask = nullptr);
+                    const unsigned long long* fan_mask = nullptr, const Igemm2Red* red = nullptr);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 bool dcfp_igemm2_use_dma8(int T, int M, int P, long long px, int sn, int sd, int off0, int offstep, int HiWi,
                           int Wo, bool pitched);

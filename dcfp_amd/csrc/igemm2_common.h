@@ -30,6 +30,14 @@ struct Igemm2Params {
                             // batched GEMM of conv_winograd.hip, where "image" xi has its own transformed filter
     int tapskip;        // 9-tap LDS-DMA kernels: K-steps of kernel rows that lie wholly in the padding for a tile are skipped
     float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
+    // igemm2_dma1p_kernel with fan_src (nullable as a group): the fan-in's OUTPUT is the gradient `g_out` arriving at the
+    // previous residual block's output; with these the epilogue also emits that block's BatchNorm-backward sums
+    //   red_part[slot][M][2] = (sum g, sum g * (red_x - red_mean[m]))  over the slot's 128 pixels,  g = g_out * red_mask bit
+    // (slot = pixel tile * 2 + wave column, as stat_part) - bn_bwd_reduce without re-reading g_out
+    const float* red_x;                    // that block's bn3 input, laid out as out
+    const unsigned long long* red_mask;    // that block's ReLU bit mask (layout of fan_mask)
+    const float* red_mean;                 // [M]
+    float* red_part;
 };
 
 namespace {

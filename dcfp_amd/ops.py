@@ -322,6 +322,8 @@ def _rp(run):
     return C.byref(run) if run is not None else None
 
 
+FANIN_RED_USED = [0]     # BatchNorm backwards that took their sums from a fan-in epilogue (tests / bench)
+FANIN_BN_SUMS = os.environ.get("DCFP_FANIN_BN_SUMS", "1") not in ("0",)   # =0: every BatchNorm backward runs its own reduce kernel (A/B)
 KEEP_XFORM = os.environ.get("DCFP_KEEP_XFORM", "1") not in ("0",)   # =0: weight gradients transform x again (A/B)
 
 
@@ -434,6 +436,48 @@ def conv2d_dgrad_fanin(dy, w, xshape, fan_src, fan_mask):
         _lib.lib().dcfp_conv2d_dgrad_fanin_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), _p(fan_src), _p(fan_mask),
                                                     _p(ws), ws.numel(), valid, _stream()), "conv2d_dgrad_fanin"))
     return dx
+
+
+def conv2d_dgrad_fanin_red_slots(w, xshape):
+    """Slot count of the fan-in form that also emits the previous block's BatchNorm-backward sums (0: not available)."""
+    if not (MASKED_FANIN and FANIN_BN_SUMS):
+        return 0
+    d = _desc(xshape, w.shape, 1, 0, 1)
+    return int(_lib.lib().dcfp_conv2d_dgrad_fanin_red_slots(C.byref(d)))
+
+
+def conv2d_dgrad_fanin_red(dy, w, xshape, fan_src, fan_mask, red_x, red_mask, red_mean, slots):
+    """conv2d_dgrad_fanin whose result dx is ALSO reduced, in the epilogue, to the BatchNorm-backward partial sums of the
+    residual block that produced this block's input: part[slot][C][2] = (sum g, sum g*(red_x - red_mean)), g = dx * the
+    bit of red_mask.  Returns (dx, part); bn_bwd_sums_from_partials finishes them."""
+    _require(dy, "dy"); _require(fan_src, "fan_src"); _require(red_x, "red_x")
+    w = w if w.is_contiguous() else w.contiguous()
+    d = _desc(xshape, w.shape, 1, 0, 1)
+    dy, ns = _batch_strided(dy)
+    if tuple(fan_src.shape) != tuple(xshape) or not fan_src.is_contiguous():
+        raise RuntimeError("conv2d_dgrad_fanin_red: fan_src must be a contiguous tensor of the input shape")
+    if tuple(red_x.shape) != tuple(xshape) or not red_x.is_contiguous() or red_mean.numel() != xshape[1]:
+        raise RuntimeError("conv2d_dgrad_fanin_red: red_x / red_mean must match the input shape")
+    dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+    part = torch.empty((slots, xshape[1], 2), dtype=torch.float32, device=dy.device)
+    ws, valid = _conv_workspace(w, _lib.CONV_DGRAD, d)
+    _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
+        _lib.lib().dcfp_conv2d_dgrad_fanin_red_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), _p(fan_src), _p(fan_mask),
+                                                        _p(red_x), _p(red_mask), _p(red_mean), _p(part), _p(ws),
+                                                        ws.numel(), valid, _stream()), "conv2d_dgrad_fanin_red"))
+    return dx, part
+
+
+def bn_bwd_sums_from_partials(part, var, eps, dgamma=None, dbeta=None):
+    """(sum_dy, sum_dy_xmu, dgamma) as bn_bwd_reduce returns them, from the partial sums of conv2d_dgrad_fanin_red."""
+    slots, Cc, _ = part.shape
+    s = torch.empty((2, Cc), dtype=torch.float32, device=part.device)
+    if dgamma is None:
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=part.device)
+    _timed("bn_bwd_reduce", None, 8.0 * part.numel() / 2, lambda: check(
+        _lib.lib().dcfp_bn_bwd_sums_from_partials_f32(_p(part), slots, Cc, _p(var), float(eps), _p(s[0]), _p(s[1]),
+                                                      _p(dgamma), _p(dbeta), _stream()), "bn_bwd_sums_from_partials"))
+    return s[0], s[1], dgamma
 
 
 def conv2d_wgrad(dy, x, wshape, stride, pad, dil, need_bias=False, dw=None, db=None, xform=None):
@@ -772,7 +816,7 @@ def bn_forward_impl(x, gamma, beta, running_mean, running_var, residual, relu, t
     return y, (mean, var, count, group)
 
 
-def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None, bparam=None, eps=1e-5):
+def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None, bparam=None, eps=1e-5, pre=None):
     """First half of the BN backward: the two per-channel sums, dgamma / dbeta written to the parameters'
     gradient slots, and (SyncBN) the exchange of the sums started asynchronously.  Returns a tuple for
     bn_backward_apply; independent kernels enqueued between the two overlap the exchange."""
@@ -786,7 +830,10 @@ def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None
     bp = bparam if bparam is not None else beta
     tg, kg = arena.grad_target(gp)
     tb, kb = arena.grad_target(bp)
-    s1, s2, _ = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu, dgamma=tg, dbeta=tb)
+    if pre is not None:     # the producer of dy already reduced it per 128 pixels (conv2d_dgrad_fanin_red): finish the sums
+        s1, s2, _ = bn_bwd_sums_from_partials(pre, var, eps, dgamma=tg, dbeta=tb)
+    else:
+        s1, s2, _ = bn_bwd_reduce(dy, x, y, mean, var, gamma, beta, eps, relu, dgamma=tg, dbeta=tb)
     dgamma = arena.grad_commit(gp, tg, kg, add_into)
     dbeta = arena.grad_commit(bp, tb, kb, add_into)
     work = None
@@ -808,14 +855,14 @@ def bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res, dx_out=None
 
 
 def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res, gparam=None, bparam=None,
-                     between=None, dx_out=None):
+                     between=None, dx_out=None, pre=None):
     """Shared backward: returns (dx, dgamma, dbeta, dres).  dgamma/dbeta are this rank's sums (None when
     they went straight into the gradient arena; the gradient all-reduce averages them); under SyncBN the
     sums entering dx are global.  `y` is only needed for the ReLU mask of a BN that had a residual input;
     otherwise the mask is re-derived from x inside the kernels (pass y=None).  between: optional callable
     run after the reduction (and the start of the SyncBN exchange) and before dx - independent work
     that hides the exchange."""
-    red = bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam, bparam, eps)
+    red = bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam, bparam, eps, pre=pre)
     mid = between() if between is not None else None
     out = bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res, dx_out)
     return out + ((mid,) if between is not None else ())
@@ -882,6 +929,8 @@ class BottleneckFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
         # tensors: w1,g1,b1, w2,g2,b2, w3,g3,b3 [, wd,gd,bd]; cfg: dict of python values + BN buffers
+        # (the block that produced x, if it left its bn3 record on the tensor: see the end of this function)
+        ctx.prev_rec = getattr(x, "_dcfp_bn3_rec", None) if FANIN_BN_SUMS else None
         x = x.contiguous()
         has_ds = len(tensors) == 12
         w1, g1, b1, w2, g2, b2, w3, g3, b3 = tensors[:9]
@@ -942,6 +991,13 @@ class BottleneckFn(torch.autograd.Function):
         # with the 1-bit mask the block output is not needed by its own backward
         keep_out = out if len(st3) <= 4 else None
         ctx.save_for_backward(x, c1, y1, c2, y2, c3, keep_out, cd, *flat)
+        # What the NEXT block needs to reduce this block's bn3 gradient in its fan-in epilogue (the gradient of `out` is
+        # that fan-in's result): bn3's input, the ReLU bit mask and the batch mean.  The record travels on the output
+        # tensor; the consumer leaves the partial sums in it and this block's backward picks them up.
+        ctx.rec = None
+        if FANIN_BN_SUMS and len(st3) > 4:
+            ctx.rec = {"c3": c3, "mask": st3[4], "mean": st3[0]}
+            out._dcfp_bn3_rec = ctx.rec
         return out
 
     @staticmethod
@@ -974,7 +1030,16 @@ class BottleneckFn(torch.autograd.Function):
         mask3 = st3[4] if len(st3) > 4 else None
         fanin = (not ctx.has_ds and mask3 is not None and ctx.needs_input_grad[0] and dout.is_contiguous()
                  and tuple(dout.shape) == tuple(x.shape) and conv2d_dgrad_fanin_ok(None, w1, tuple(x.shape)))
-        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], not fanin)
+        # bn3's sums may already sit in this block's record, reduced per 128 pixels by the fan-in that produced dout - but
+        # only if dout IS that fan-in's result (autograd adds other consumers' gradients into a new tensor, or in place
+        # with a version bump: either way the partial sums would be of something else)
+        pre, rec = None, getattr(ctx, "rec", None)
+        if rec is not None:
+            part, ptr, ver = rec.pop("part", None), rec.pop("dx_ptr", None), rec.pop("dx_ver", None)
+            if part is not None and dout.data_ptr() == ptr and dout._version == ver and dout.is_contiguous():
+                pre = part
+                FANIN_RED_USED[0] += 1
+        d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], not fanin, pre=pre)
         d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
         # conv3's weight gradient does not feed bn2: it runs between bn2's reduction and its dx
         dc2_out = pitched_buffer(tuple(c2.shape), ctx.pitch, "d_c2", c2.device) if ctx.pitch else None
@@ -995,7 +1060,16 @@ class BottleneckFn(torch.autograd.Function):
             dw1, _ = wgrad_into_param(d_c1, x, w1, None, 1, 0, 1)
             dx = d_res
         grads[0] = dw1
-        if fanin:
+        prev = ctx.prev_rec
+        slots = 0
+        if fanin and prev is not None and tuple(prev["c3"].shape) == tuple(x.shape):
+            slots = conv2d_dgrad_fanin_red_slots(w1, tuple(x.shape))
+        if fanin and slots > 0:
+            # dx is the gradient arriving at the previous block's output: reduce it for that block's bn3 on the way out
+            dx, part = conv2d_dgrad_fanin_red(d_c1, w1, tuple(x.shape), dout, mask3, prev["c3"], prev["mask"],
+                                              prev["mean"], slots)
+            prev["part"], prev["dx_ptr"], prev["dx_ver"] = part, dx.data_ptr(), dx._version
+        elif fanin:
             dx = conv2d_dgrad_fanin(d_c1, w1, tuple(x.shape), dout, mask3)
         elif ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(d_c1, w1, tuple(x.shape), 1, 0, 1, out=dx, accumulate=True)

@@ -136,6 +136,22 @@ int dcfp_conv2d_dgrad_fanin_supported(const DcfpConvDesc* d);
 int dcfp_conv2d_dgrad_fanin_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride, const float* w, float* dx,
                                      const float* fan_src, const void* fan_mask, void* workspace, size_t workspace_bytes,
                                      int wp_valid, dcfp_stream_t stream);
+/* The same fan-in that ALSO emits the BatchNorm-backward sums of the PREVIOUS residual block (resnet.py:41-56 backward):
+ * dx, this call's result, is the gradient arriving at that block's output; with that block's bn3 input `red_x` (laid
+ * out as dx), its ReLU bit mask `red_mask` (layout of dcfp_bn_apply_relu_mask_f32) and batch mean `red_mean[Cin]` the
+ * epilogue writes red_part[slot][Cin][2] = (sum g, sum g*(x - mean)) over 128 pixels each, g = dx * mask bit;
+ * dcfp_bn_bwd_sums_from_partials_f32 reduces the slots in a fixed order in fp64 to exactly the outputs of
+ * dcfp_bn_bwd_reduce_f32 (sum_dy, sum_dy_xmu, dgamma, dbeta) - that block's backward then skips its reduce kernel and
+ * never re-reads dx (8 B/element less).  dcfp_conv2d_dgrad_fanin_red_slots: the slot count N*H*W/128 where this form
+ * exists (fan-in supported AND the launch takes the 128-row tiles, Cout <= 256), else 0. */
+int64_t dcfp_conv2d_dgrad_fanin_red_slots(const DcfpConvDesc* d);
+int dcfp_conv2d_dgrad_fanin_red_f32_nchw(const DcfpConvDesc* d, const float* dy, int64_t dy_nstride, const float* w,
+                                         float* dx, const float* fan_src, const void* fan_mask, const float* red_x,
+                                         const void* red_mask, const float* red_mean, float* red_part, void* workspace,
+                                         size_t workspace_bytes, int wp_valid, dcfp_stream_t stream);
+int dcfp_bn_bwd_sums_from_partials_f32(const float* partials, int64_t slots, int C, const float* var, float eps,
+                                       float* sum_dy, float* sum_dy_xmu, float* dgamma /* nullable */,
+                                       float* dbeta /* nullable */, dcfp_stream_t stream);
 
 /* Name of the kernel instance a pass dispatches for this descriptor, e.g.
  * "igemm_kernel<9,4,4,2,2,0>" (template args: taps, TM, TN, WM, WN[, strided-dgrad]) — the

@@ -403,7 +403,9 @@ def test_masked_fanin_bit_identical_to_materialised_residual_gradient(cuda):
     res = []
     for v in ("0", "1"):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env = dict(os.environ, DCFP_MASKED_FANIN=v, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        # (DCFP_FANIN_BN_SUMS=0: the fan-in's BatchNorm-sums side output reorders bn3's sums - tested on its own below)
+        env = dict(os.environ, DCFP_MASKED_FANIN=v, DCFP_FANIN_BN_SUMS="0",
+                   PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fanin-child"], env=env, capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -415,6 +417,65 @@ def test_masked_fanin_bit_identical_to_materialised_residual_gradient(cuda):
 if __name__ == "__main__" and "--fanin-child" in __import__("sys").argv:
     __import__("sys").path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _fanin_child()
+
+
+def test_fanin_epilogue_bn_sums(cuda):
+    """The fan-in dgrad that also reduces its result for the previous block's bn3 (ops.conv2d_dgrad_fanin_red):
+    dx the same bits as the plain fan-in, the finished sums against an fp64 evaluation from the mask bits and against
+    the bn_bwd_reduce kernel they replace; then a DeepLabv3-R50 step at 2x3x512x1024 with and without the coupling:
+    the coupled path must actually be taken and move no parameter gradient by more than fp32 summation noise."""
+    from dcfp_amd import ops
+    dev = cuda
+    g = torch.Generator().manual_seed(3)
+    N, Cin, Cout, H, W = 2, 1024, 256, 64, 128                     # layer3 conv1 geometry at 2x3x512x1024
+    xs = (N, Cin, H, W)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    dy, w, fan_src = rnd(N, Cout, H, W), rnd(Cout, Cin, 1, 1) * 0.05, rnd(*xs)
+    gam, bet = torch.rand(Cin, generator=g).to(dev) + 0.5, rnd(Cin) * 0.1
+    c3, res = rnd(*xs) * 1.5 + 0.3, rnd(*xs)
+    mean, var = ops.bn_stats(c3)
+    _, mask = ops.bn_apply_relu_mask(c3, mean, var, gam, bet, 1e-5, res)
+    c3b, resb = rnd(*xs) * 0.7 - 0.2, rnd(*xs)
+    mean_b, var_b = ops.bn_stats(c3b)
+    yb, mask_b = ops.bn_apply_relu_mask(c3b, mean_b, var_b, gam, bet, 1e-5, resb)
+    slots = ops.conv2d_dgrad_fanin_red_slots(w, xs)
+    assert slots == N * H * W // 128
+    dx0 = ops.conv2d_dgrad_fanin(dy, w, xs, fan_src, mask)
+    dx1, part = ops.conv2d_dgrad_fanin_red(dy, w, xs, fan_src, mask, c3b, mask_b, mean_b, slots)
+    assert torch.equal(dx0, dx1)
+    s1, s2, dg = ops.bn_bwd_sums_from_partials(part, var_b, 1e-5)
+    gd = dx0.double() * (yb > 0).double()                          # yb = relu(...): positive exactly where the bit is set
+    t1 = gd.sum(dim=(0, 2, 3))
+    t2 = (gd * (c3b.double() - mean_b.double().view(1, -1, 1, 1))).sum(dim=(0, 2, 3))
+    rel = lambda a, t: float((a.double() - t).norm() / t.norm())
+    assert rel(s1, t1) < 2e-6 and rel(s2, t2) < 2e-6, (rel(s1, t1), rel(s2, t2))
+    assert rel(dg, t2 * torch.rsqrt(var_b.double() + 1e-5)) < 2e-6
+    r1, r2, _ = ops.bn_bwd_reduce(dx0, c3b, mask_b, mean_b, var_b, gam, bet, 1e-5, 3)
+    assert rel(s1, r1.double()) < 2e-6 and rel(s2, r2.double()) < 2e-6
+
+    def step(flag):
+        ops.FANIN_BN_SUMS = flag
+        ops.FANIN_RED_USED[0] = 0
+        m = build("deeplabv3", "resnet50", True, dev)
+        m.conv_deepsup[3].p = 0.0
+        gg = torch.Generator().manual_seed(21)
+        x = torch.randn(2, 3, 512, 1024, generator=gg).to(dev)
+        lab = torch.randint(0, 19, (2, 512, 1024), generator=gg).to(dev)
+        loss = m(x, lab, deepsup=True)["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, ops.FANIN_RED_USED[0]
+    saved = ops.FANIN_BN_SUMS
+    try:
+        l0, g0, n0 = step(False)
+        l1, g1, n1 = step(True)
+    finally:
+        ops.FANIN_BN_SUMS = saved
+    assert n0 == 0 and n1 >= 5, (n0, n1)          # layer3 of R50: 5 identity blocks behind an identity-or-downsample block
+    assert l0 == l1
+    a = torch.cat([v.reshape(-1).double() for v in g0.values()])
+    b = torch.cat([g1[k].reshape(-1).double() for k in g0])
+    assert float((a - b).norm() / a.norm()) < 1e-4          # (wrong sums would be O(1); reordered fp32 sums are ~1e-6)
 
 
 def test_dropped_graph_releases_the_pitched_buffers(cuda, monkeypatch):
