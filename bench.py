@@ -124,12 +124,15 @@ def cpu_baseline(backbone, n, h, w, full_hw, reps=3):
 def roofline_from_profile(recs, images_per_step, step_s):
     """Aggregate one instrumented step by kernel instance; the dominant one (by time) is reported."""
     from dcfp_amd import ops, _lib
-    which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD}
+    which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD,
+             "conv_dgrad_red": _lib.CONV_DGRAD}
     agg = {}
     conv_flops = conv_ms = bn_bytes = bn_ms = 0.0
     for kind, key, work, ms in recs:
         if kind in which:
             name = ops.conv_kernel_name(key, which[kind])
+            if kind == "conv_dgrad_red":      # the fan-in launches that also reduce the previous block's bn3 gradient
+                name += " + bn3 sums epilogue"
             a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
             a[0] += work; a[1] += ms; a[2] += 1
             a[3] += work * ops.conv_executed_fraction(key, which[kind])     # MFMA work really issued

@@ -461,7 +461,8 @@ def conv2d_dgrad_fanin_red(dy, w, xshape, fan_src, fan_mask, red_x, red_mask, re
     dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
     part = torch.empty((slots, xshape[1], 2), dtype=torch.float32, device=dy.device)
     ws, valid = _conv_workspace(w, _lib.CONV_DGRAD, d)
-    _timed("conv_dgrad", d, _conv_flops(d), lambda: check(
+    # (its own profile kind: the launch also does the previous block's BatchNorm reduction - bench.py lists it apart)
+    _timed("conv_dgrad_red", d, _conv_flops(d), lambda: check(
         _lib.lib().dcfp_conv2d_dgrad_fanin_red_f32_nchw(C.byref(d), _p(dy), ns, _p(w), _p(dx), _p(fan_src), _p(fan_mask),
                                                         _p(red_x), _p(red_mask), _p(red_mean), _p(part), _p(ws),
                                                         ws.numel(), valid, _stream()), "conv2d_dgrad_fanin_red"))
@@ -1039,6 +1040,10 @@ class BottleneckFn(torch.autograd.Function):
             if part is not None and dout.data_ptr() == ptr and dout._version == ver and dout.is_contiguous():
                 pre = part
                 FANIN_RED_USED[0] += 1
+            # the record's references must not outlive this backward: the node object (ctx) stays until the whole graph
+            # is dropped, and 33 blocks' bn3 inputs held that long are 14 GB of peak memory
+            rec.clear()
+            ctx.rec = None
         d_c3, dg3, db3, d_res = bn_backward_impl(dout, c3, out, g3, b3, st3, True, training[2], eps[2], not fanin, pre=pre)
         d_y2 = conv2d_dgrad(d_c3, w3, tuple(y2.shape), 1, 0, 1)
         # conv3's weight gradient does not feed bn2: it runs between bn2's reduction and its dx
@@ -1069,12 +1074,14 @@ class BottleneckFn(torch.autograd.Function):
             dx, part = conv2d_dgrad_fanin_red(d_c1, w1, tuple(x.shape), dout, mask3, prev["c3"], prev["mask"],
                                               prev["mean"], slots)
             prev["part"], prev["dx_ptr"], prev["dx_ver"] = part, dx.data_ptr(), dx._version
+            del part
         elif fanin:
             dx = conv2d_dgrad_fanin(d_c1, w1, tuple(x.shape), dout, mask3)
         elif ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(d_c1, w1, tuple(x.shape), 1, 0, 1, out=dx, accumulate=True)
         else:
             dx = None
+        ctx.prev_rec = None
         if ctx.pitch_slot is not None:
             ctx.pitch_slot.release()            # y1's buffer may be reused by the next forward of this block
         return (dx, None) + tuple(grads)

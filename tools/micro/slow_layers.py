@@ -15,7 +15,7 @@ def step():
 for _ in range(2): step()
 torch.cuda.synchronize()
 ops.profile_start(); step(); recs = ops.profile_stop()
-which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD}
+which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD, "conv_dgrad_red": _lib.CONV_DGRAD}
 agg = {}
 for kind, key, work, ms in recs:
     if kind in which:

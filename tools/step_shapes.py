@@ -36,7 +36,7 @@ def main():
     ops.profile_start()
     step(2)
     recs = ops.profile_stop()
-    which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD}
+    which = {"conv_fwd": _lib.CONV_FWD, "conv_dgrad": _lib.CONV_DGRAD, "conv_wgrad": _lib.CONV_WGRAD, "conv_dgrad_red": _lib.CONV_DGRAD}
     agg = defaultdict(lambda: [0.0, 0.0, 0, ""])
     for kind, key, work, ms in recs:
         if kind not in which:
