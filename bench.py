@@ -487,9 +487,7 @@ def main():
         json_out.flush()
     if dist.is_initialized():
         from dcfp_amd import syncbn_p2p
-        for px in list(syncbn_p2p._ACTIVE.values()):
-            px.check()                 # an exchange that gave up on a peer is an error, not a number
-        syncbn_p2p.disable()
+        syncbn_p2p.finish()            # an exchange that gave up on a peer is an error, not a number
         dist.destroy_process_group()
 
 

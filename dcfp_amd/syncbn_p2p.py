@@ -185,3 +185,12 @@ def disable(group=None):
         px = _ACTIVE.pop(g, None)
         if px is not None:
             px.close()
+
+
+def finish():
+    """End of a run: raise if any exchange gave up on a peer, then release every mailbox (bench.py, tools/train.py)."""
+    try:
+        for px in list(_ACTIVE.values()):
+            px.check()
+    finally:
+        disable()

@@ -143,9 +143,7 @@ def main(argv=None):
         if main_flag and train_pruning is not None:
             train_pruning.export_eic(osp.join(args.snapshot_dir, "score.pth"))
         from dcfp_amd import syncbn_p2p
-        for px in list(syncbn_p2p._ACTIVE.values()):    # DCFP_SYNCBN_P2P=1: no exchange may have given up on a peer
-            px.check()
-        syncbn_p2p.disable()
+        syncbn_p2p.finish()            # DCFP_SYNCBN_P2P=1: no exchange may have given up on a peer
 
 
 if __name__ == "__main__":
