@@ -86,10 +86,17 @@ def host_cores():
     return max(1, min(n, cap))
 
 
+def host_ram_gib():
+    try:
+        return os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
+    except (ValueError, OSError):
+        return None
+
+
 def cpu_baseline(backbone, n, h, w, full_hw, reps=3):
     """The CPU oracle (a port of the reference's CPU path) on a bounded sample: the same model
     at batch `n` (ASPP image-pool BN needs >= 2) and h x w pixels; images/s are scaled by the
-    pixel ratio to the full 1024x2048 workload."""
+    pixel ratio to the full 1024x2048 workload (`extrapolated` says whether that ratio is not 1)."""
     from dcfp_amd import networks
     from oracle import model as omodel
     from oracle.train_step import CpuTrainer
@@ -115,10 +122,14 @@ def cpu_baseline(backbone, n, h, w, full_hw, reps=3):
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
     scale = (h * w) / float(full_hw[0] * full_hw[1])
+    ram = host_ram_gib()
     return {"value": (n / dt) * scale, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"median of {reps} steps (after 1 warm-up step) of the CPU oracle (oracle/train_step.py), "
-                      f"DeepLabv3-{backbone} batch {n} at {h}x{w} ({dt:.1f} s per step), images/s scaled by the pixel "
-                      f"ratio {scale:.4f} to 1024x2048", "step_s": times}
+            "extrapolated": scale != 1.0, "host_ram_GiB": None if ram is None else round(ram, 1),
+            "sample": f"median of {reps} step(s) (after 1 warm-up step) of the CPU oracle (oracle/train_step.py), "
+                      f"DeepLabv3-{backbone} batch {n} at {h}x{w} ({dt:.1f} s per step)" +
+                      (f", images/s scaled by the pixel ratio {scale:.4f} to {full_hw[0]}x{full_hw[1]}" if scale != 1.0 else
+                       ", the full resolution: per-image rate of a batch-2 step, nothing scaled (BASELINE.md section 3)"),
+            "step_s": times}
 
 
 def roofline_from_profile(recs, images_per_step, step_s):
@@ -182,6 +193,14 @@ def roofline_from_profile(recs, images_per_step, step_s):
                if wino else {}),
             "dtype": "f32 as 3 bf16 planes (6 x v_mfma_f32_32x32x16_bf16 per product)" if split
                      else "f32 (v_mfma_f32_32x32x2_f32)"}
+    # the whole family of the dominant kernel (every launch whose entry name starts with the same kernel: for the 1x1 convs
+    # also the fan-in launches that carry the bn3 sums epilogue and are listed as an entry of their own) - the figure that
+    # stays like for like from round to round
+    fam_key = dom.split("<")[0].split(" ")[0]
+    fam = [v for k, v in convs.items() if k.startswith(fam_key)]
+    fw, fms, fcnt = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
+    roof.update({"family": fam_key, "family_frac": fw / (fms * 1e-3) / peak, "family_TFLOP/s": fw / (fms * 1e-3) / 1e12,
+                 "family_launches_per_step": fcnt, "family_ms_per_step": fms})
     others = {k: {"TFLOP/s": v[0] / (v[1] * 1e-3) / 1e12, "executed_TFLOP/s": v[3] / (v[1] * 1e-3) / 1e12,
                   "ms_per_step": v[1], "launches": v[2]}
               for k, v in sorted(convs.items(), key=lambda kv: -kv[1][1])}
@@ -297,7 +316,9 @@ def main():
     ap.add_argument("--size", default="1024,2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample", default="2,512,1024", help="n,h,w of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="auto",
+                    help="n,h,w of the CPU baseline sample; auto = batch 2 at the full resolution when host RAM >= 150 GiB, "
+                         "else 2,512,1024 scaled by the pixel ratio")
     ap.add_argument("--channel-cfg", default=None,
                     help="time the slim model described by this channel_cfg.pth instead (not the headline config)")
     ap.add_argument("--alt-legs", action="store_true",
@@ -342,7 +363,7 @@ def main():
     if args.syncbn_p2p:
         os.environ["DCFP_SYNCBN_P2P"] = "1"
 
-    from dcfp_amd import optimizer as opt, pruners, ops
+    from dcfp_amd import optimizer as opt, pruners, ops, syncbn_p2p
     from dcfp_amd.engine import Engine
     torch.manual_seed(12345 + rank)           # train.py:166-171
     seg_model = build_model(args.backbone, device, args.channel_cfg)
@@ -363,6 +384,9 @@ def main():
         loss = model(images, labels, deepsup=True)
         reduce_loss = engine.all_reduce_tensor(loss["loss"]) if ddp else loss["loss"]
         val = reduce_loss.item()              # the reference syncs here every iteration (train.py:263)
+        # the peer-to-peer SyncBN exchange poisons its outputs with NaN when it gives up on a peer: ask it first, so that
+        # the message names the exchange and the rank (no-op unless --syncbn-p2p; one 4-byte read beside the sync above)
+        syncbn_p2p.check_all()
         if val != val:
             raise RuntimeError("loss is NaN")
         loss["loss"].backward()
@@ -412,13 +436,18 @@ def main():
             # is left of them is the wait at the end of backward; `alone` = the same all-reduces with nothing to overlap.
             kinds = ("syncbn_allgather", "syncbn_p2p_fwd")
             sync = [ms for (kind, _, _, ms) in recs if kind in kinds]
+            # backward: the exchange of [sum g, sum g (x - mean)] runs beside the weight gradient enqueued behind it; what
+            # the compute stream still waits for (event pair around each wait) and the synchronous ones (no weight gradient
+            # to hide behind: p2p kernel on the compute stream)
+            bwd_wait = [ms for (kind, _, _, ms) in recs if kind in ("syncbn_bwd_wait", "syncbn_p2p_bwd")]
             exposed = reducer.exposed_ms()
             alone = reducer.alone_ms()
             comm = {"syncbn_exposed_ms": sum(sync), "syncbn_allgathers": len(sync),
+                    "syncbn_bwd_exposed_ms": sum(bwd_wait), "syncbn_bwd_exchanges": len(bwd_wait),
                     "syncbn_exchange": "p2p kernel" if any(r[0] == "syncbn_p2p_fwd" for r in recs) else "rccl",
                     "grad_allreduce_ms": alone, "grad_allreduce_exposed_ms": exposed,
                     "allreduce_overlapped_frac": (1.0 - exposed / alone) if (alone and exposed is not None) else None}
-            recs = [r for r in recs if r[0] not in kinds]
+            recs = [r for r in recs if r[0] not in kinds + ("syncbn_bwd_wait", "syncbn_p2p_bwd")]
         if rank == 0:
             roof, extra = roofline_from_profile(recs, args.batch, step_s)
     fence()
@@ -427,8 +456,15 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n, h, w = [int(v) for v in args.cpu_sample.split(",")]
-        cpu = cpu_baseline(args.backbone, n, h, w, (H, W))
+        if args.cpu_sample == "auto":
+            # batch 2 per image; at the FULL resolution when the host has the memory for it
+            # (R101 batch 2 at 1024x2048 keeps ~40 GB of activations in fp32), else at 512x1024 scaled by the pixel ratio
+            ram = host_ram_gib() or 0.0
+            full = ram >= 150.0 and (H, W) == (1024, 2048)
+            n, h, w, reps = (2, H, W, 1) if full else (2, 512, 1024, 3)
+        else:
+            (n, h, w), reps = [int(v) for v in args.cpu_sample.split(",")], 3
+        cpu = cpu_baseline(args.backbone, n, h, w, (H, W), reps)
 
     # Reported beside the headline, never as it: the same step with the opt-in 3-way bf16 split
     # conv kernels (fp32-grade products on the bf16 matrix cores; DESIGN.md "bf16x3").  The library

@@ -76,6 +76,7 @@ bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_
 size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
 size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
 bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d);      // conv_wgrad.hip
+bool dcfp_wgrad_wants_xform(const DcfpConvDesc* d);
 long long dcfp_igemm2_stat_slots(int M, int P, int N, long long out_nstride, const float* out);
 bool dcfp_igemm2_dma_shape(int T, int M, int Ck, int P, long long px, int sn, int sd, int off0, int HiWi, int Wo);
 bool dcfp_igemm2_persist();
@@ -165,7 +166,7 @@ extern "C" int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass)
     return wino_pass(d, pass) ? 1 : 0;
 }
 
-extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
+size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK) return 0;
     if (const int wk = wino_kind(d, pass)) {
         const int M = pass == DCFP_CONV_FWD ? d->Cout : d->Cin, Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
@@ -247,7 +248,7 @@ extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float
 // (dcfp_conv2d_wgrad_kept_f32_nchw) instead of transforming x again; 0 where either pass is not Winograd.
 extern "C" size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d) {
     if (check_desc(d) != DCFP_OK) return 0;
-    if (!wino_pass(d, DCFP_CONV_FWD) || !dcfp_wgrad_is_winograd(d)) return 0;
+    if (!wino_pass(d, DCFP_CONV_FWD) || !dcfp_wgrad_wants_xform(d)) return 0;
     return dcfp_wino_xform_bytes(d->N, d->H, d->W, d->dil, d->Cin);
 }
 

@@ -951,9 +951,12 @@ int dcfp_wgrad_batched_run(const float* a, const float* bmat, float* out, int ba
 }
 
 static bool wino_wgrad_pass(const DcfpConvDesc* d);
+static int wino_wgrad_kind(const DcfpConvDesc* d);
 
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
-    if (wino_wgrad_pass(d)) return snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false,false,true>)");
+    if (const int wk = wino_wgrad_kind(d))
+        return wk == 2 ? snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad fused (wino_wgrad_fused_kernel)")
+                       : snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false,false,true>)");
     const Plan pl = make_plan(d);
     const char* args = pl.cfg == 0 ? "4,4,2,2" : pl.cfg == 1 ? "2,4,2,2" : pl.cfg == 3 ? "4,2,2,2" :
                        pl.cfg == 4 ? "4,1,2,2" : pl.cfg == 5 ? "2,3,2,2" : "2,2,1,1";
@@ -974,45 +977,91 @@ int dcfp_wino_wgrad_run(const float* dy, long long dy_nstride, int dy_pitch, con
                         size_t workspace_bytes, hipStream_t stream, const float* xform_in = nullptr);
 extern "C" size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d);
 
-// Winograd F(2x2, 3x3) weight gradient where the cost model (same-box measurements, profiles/r02_winograd_ab.txt) says
-// it beats the direct LDS-DMA kernel: direct = nominal FLOPs at 130 TF (123 on dense dilation-1 operands);
-// Winograd = 16/36 x tile padding of them at 125 TF plus the x / dy transform passes at 4.2 / 5 TB/s.
-// DCFP_CONV_WINOGRAD: 0 off, 1 model (default), 2 wherever eligible.
-static bool wino_wgrad_pass(const DcfpConvDesc* d) {
+// executed-MFMA rate the cost model prices the fused Winograd weight gradient at (DCFP_WINO_WGRAD_RATE, TF: A/B), and
+// DCFP_WINO_WGRAD_FUSED=2: take it wherever it applies and beats the direct kernel, whatever the batched path's model says
+static double wino_wgrad_fused_rate() {
+    static const double v = [] { const char* e = getenv("DCFP_WINO_WGRAD_RATE"); return (e ? atof(e) : 118.0) * 1e12; }();
+    return v;
+}
+static bool wino_wgrad_fused_forced() {
+    static const bool v = [] { const char* e = getenv("DCFP_WINO_WGRAD_FUSED"); return e && atoi(e) == 2; }();
+    return v;
+}
+
+// conv_winograd3.hip: the fused weight-gradient kernel (both operands transformed inside the GEMM, no kept V)
+bool dcfp_wino_wgrad_fused_ok(int N, int H, int W, int d, int M, int C, long long x_nstride, int x_pitch,
+                              long long dy_nstride, int dy_pitch);
+size_t dcfp_wino_wgrad_fused_workspace_bytes(int N, int H, int W, int d, int M, int C);
+int dcfp_wino_wgrad_fused_run(const float* dy, long long dy_nstride, int dy_pitch, const float* x, long long x_nstride,
+                              int x_pitch, float* dw, int N, int M, int C, int H, int W, int d, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream);
+
+// Winograd F(2x2, 3x3) weight gradient where the cost model (same-box measurements, profiles/r02_winograd_ab.txt,
+// profiles/r04_wino_wgrad_fused_ab.txt) says it beats the direct LDS-DMA kernel: direct = nominal FLOPs at 130 TF (123 on
+// dense dilation-1 operands); batched Winograd (kind 1) = 16/36 x tile padding of them at 125 TF plus the x / dy transform
+// passes at 4.2 / 5 TB/s; fused Winograd (kind 2, conv_winograd3.hip) = the same products on 64 x 64-channel blocks at the
+// rate of its K loop, no passes - the only Winograd weight gradient below 128 channels (stem, layer1, layer2, pruned widths).
+// Returns 0 (direct kernels), 1 or 2.  DCFP_CONV_WINOGRAD: 0 off, 1 model (default), 2 wherever eligible.
+static int wino_wgrad_kind(const DcfpConvDesc* d) {
     static const int mode = [] { const char* e = getenv("DCFP_CONV_WINOGRAD"); return e ? atoi(e) : 1; }();
-    if (mode == 0) return false;
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->Hout != d->H || d->Wout != d->W) return false;
-    if (math_bf16x3()) return false;
-    if (!dcfp_wino_wgrad_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)) return false;
-    if (mode == 2) return true;
+    if (mode == 0) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->Hout != d->H || d->Wout != d->W) return 0;
+    if (math_bf16x3()) return 0;
+    const int xp = d->x_pitch ? d->x_pitch : d->W, dyp = d->dy_pitch ? d->dy_pitch : d->Wout;
+    const bool batched = dcfp_wino_wgrad_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
+    // (a dy that is a channel slice of a wider tensor - the ASPP branches - has its own image stride: the entry point
+    //  checks the real one again)
+    const bool fused = dcfp_wino_wgrad_fused_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin, (long long)d->Cin * d->H * xp, xp,
+                                                (long long)d->Cout * d->Hout * dyp, dyp);
+    if (!batched && !fused) return 0;
+    if (mode == 2) return fused ? 2 : 1;
     const double pix = (double)d->N * d->H * d->W;
     const double nominal = 2.0 * pix * d->Cout * (double)d->Cin * 9.0;
     const bool dense_d1 = wgrad_dma_mixed(d) && !(d->x_pitch && d->x_pitch != d->W);
     const bool ragged = d->Cout % 256 != 0 || (d->Cin * 9) % 256 != 0;      // the direct kernel pays for its tile padding too
     const double dpad = ragged ? (double)((d->Cout + 31) / 32 * 32) / d->Cout * (double)((d->Cin * 9 + 255) / 256 * 256) / (d->Cin * 9) * 1.15
                                : 1.0;     // (x 1.15: the 8 x 2 wave layout of the ragged-M kernel)
-    const double t_direct = nominal * dpad / (dense_d1 ? 123e12 : 130e12);
+    // (below 128 output channels the direct path is the register-staged wgrad2_kernel: 82...110 TF measured)
+    const double t_direct = nominal * dpad / (d->Cout < 128 ? 100e12 : dense_d1 ? 123e12 : 130e12);
     const double f = dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
-    const double tiles = f * 9.0 / 16.0 * pix;
-    const double pad2 = (double)((d->Cout + 255) / 256 * 256) / d->Cout * (double)((d->Cin + 255) / 256 * 256) / d->Cin;
-    const double t_wino = nominal * f * pad2 / 125e12 + (4.0 * pix * d->Cin + 64.0 * tiles * d->Cin) / 4.2e12 +
-                          (4.0 * pix * d->Cout + 64.0 * tiles * d->Cout) / 5.0e12 + 30e-6;
-    return t_wino < 0.97 * t_direct;
+    double t_b = 1e30, t_f = 1e30;
+    if (batched) {
+        const double tiles = f * 9.0 / 16.0 * pix;
+        const double pad2 = (double)((d->Cout + 255) / 256 * 256) / d->Cout * (double)((d->Cin + 255) / 256 * 256) / d->Cin;
+        t_b = nominal * f * pad2 / 125e12 + (4.0 * pix * d->Cin + 64.0 * tiles * d->Cin) / 4.2e12 +
+              (4.0 * pix * d->Cout + 64.0 * tiles * d->Cout) / 5.0e12 + 30e-6;
+    }
+    if (fused) {
+        const double pad64 = (double)((d->Cout + 63) / 64 * 64) / d->Cout * (double)((d->Cin + 63) / 64 * 64) / d->Cin;
+        t_f = nominal * f * pad64 / wino_wgrad_fused_rate() + 15e-6;
+    }
+    if (fused && (t_f <= t_b || wino_wgrad_fused_forced())) return t_f < 0.97 * t_direct ? 2 : 0;
+    return t_b < 0.97 * t_direct ? 1 : 0;
 }
+static bool wino_wgrad_pass(const DcfpConvDesc* d) { return wino_wgrad_kind(d) != 0; }
 
 bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d) { return wino_wgrad_pass(d); }
+// ... and needs the forward's transformed input V (the batched path; the fused kernel transforms x itself)
+bool dcfp_wgrad_wants_xform(const DcfpConvDesc* d) { return wino_wgrad_kind(d) == 1; }
 
 // share of the nominal multiply-adds issued (the direct kernels execute every K-step: a tile of dW mixes all nine taps)
 double dcfp_wgrad_exec_fraction(const DcfpConvDesc* d) {
     return wino_wgrad_pass(d) ? dcfp_wino_exec_fraction(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) : 1.0;
 }
 
-extern "C" size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
+size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
 
 extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
     if (pass == DCFP_CONV_FWD || pass == DCFP_CONV_DGRAD) return dcfp_conv2d_fwd_dgrad_workspace_bytes_(d, pass);
     if (pass != DCFP_CONV_WGRAD || check_desc(d) != DCFP_OK) return 0;
-    if (wino_wgrad_pass(d)) return dcfp_wino_wgrad_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
+    if (const int wk = wino_wgrad_kind(d)) {
+        // (kind 2 can fall back to the batched path at run time - a dy slice whose image stride breaks the 31-bit offsets -
+        //  so the query covers both where both apply)
+        const size_t b1 = dcfp_wino_wgrad_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)
+                              ? dcfp_wino_wgrad_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) : 0;
+        const size_t b2 = wk == 2 ? dcfp_wino_wgrad_fused_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) : 0;
+        return wk == 2 ? b2 : b1;
+    }
     const Plan pl = make_plan(d);
     if (pl.splits <= 1) return 0;
     return (size_t)pl.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
@@ -1027,13 +1076,19 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (!dy || !x || !dw) return DCFP_E_BADDESC;
     if (dcfp_gemv_shape(d) && !db)      // a 1x1 conv on a 1 x 1 map (ASPP image pool): conv_gemv.hip
         return dcfp_gemv_wgrad(d, dy, dy_nstride, x, dw, dcfp_s(stream));
-    if (wino_wgrad_pass(d)) {
+    if (const int wk = wino_wgrad_kind(d)) {
         const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout, xp = d->x_pitch ? d->x_pitch : d->W;
         const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;
-        rc = dcfp_wino_wgrad_run(dy, dyn, dyp, x, (long long)d->Cin * d->H * xp, xp, dw, d->N, d->Cout, d->Cin, d->H, d->W,
-                                 d->dil, workspace, workspace_bytes, dcfp_s(stream));
+        if (db && dyp != d->Wout) return DCFP_E_UNSUPPORTED;      // (the bias-gradient kernel reads dense rows; nothing launched yet)
+        if (wk == 2) {
+            if (!dcfp_wino_wgrad_fused_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin, (long long)d->Cin * d->H * xp, xp, dyn, dyp))
+                return DCFP_E_UNSUPPORTED;                        // (a dy slice too far apart for 31-bit offsets)
+            rc = dcfp_wino_wgrad_fused_run(dy, dyn, dyp, x, (long long)d->Cin * d->H * xp, xp, dw, d->N, d->Cout, d->Cin, d->H,
+                                           d->W, d->dil, workspace, workspace_bytes, dcfp_s(stream));
+        } else
+            rc = dcfp_wino_wgrad_run(dy, dyn, dyp, x, (long long)d->Cin * d->H * xp, xp, dw, d->N, d->Cout, d->Cin, d->H, d->W,
+                                     d->dil, workspace, workspace_bytes, dcfp_s(stream));
         if (rc) return rc;
-        if (db && dyp != d->Wout) return DCFP_E_UNSUPPORTED;      // (the bias-gradient kernel reads dense rows)
         if (db)
             hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(1024), 0, dcfp_s(stream), dy, dyn, db, d->N,
                                d->Hout * d->Wout, (int)((d->Hout * d->Wout) % 4 == 0 && dyn % 4 == 0 && dcfp_aligned16(dy)));
@@ -1051,6 +1106,7 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     p.dy_pitch = d->dy_pitch ? d->dy_pitch : d->Wout;
     const bool pitched = p.x_pitch != d->W || p.dy_pitch != d->Wout;
     if (pitched && !dcfp_wgrad_pitch_ok(d)) return DCFP_E_UNSUPPORTED;
+    if (db && p.dy_pitch != d->Wout) return DCFP_E_UNSUPPORTED;   // (the bias-gradient kernel reads dense rows) - before anything is launched
     p.dy_nstride = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * p.dy_pitch;
     p.x_nstride = (long long)d->Cin * d->H * p.x_pitch;
     p.N = d->N; p.M = d->Cout; p.Cin = d->Cin; p.Nn = d->Cin * T;
@@ -1096,7 +1152,6 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
                                static_cast<const float*>(workspace), dw, wn, pl.splits);
         }
     }
-    if (db && p.dy_pitch != d->Wout) return DCFP_E_UNSUPPORTED;   // (the bias-gradient kernel reads dense rows)
     if (db) {
         hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)d->Cout), dim3(1024), 0, dcfp_s(stream),
                            dy, p.dy_nstride, db, d->N, p.P,

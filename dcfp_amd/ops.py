@@ -849,7 +849,9 @@ def bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam=None
 def bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res, dx_out=None):
     s1, s2, work, relu, y, dgamma, dbeta = red
     if work is not None:
-        work.wait()
+        # (bench.py sums these: how long the compute stream stands still for a backward SyncBN exchange that the weight
+        #  gradient enqueued in between did not hide - comm.syncbn_bwd_exposed_ms)
+        _timed("syncbn_bwd_wait", None, 0.0, work.wait)
     mean, var, count = state[:3]
     dx, dres = bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, want_res, dx_out)
     return dx, dgamma, dbeta, dres

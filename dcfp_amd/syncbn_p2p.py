@@ -38,11 +38,13 @@ class _StreamWork:
     """What sync_bn_bwd_sums hands back for an exchange launched on the side stream: wait() makes the
     current stream wait for it (the interface of the c10d Work the RCCL path returns)."""
 
-    def __init__(self, event):
+    def __init__(self, event, held):
         self.event = event
+        self.held = held      # the exchange's input and output: alive (and out of the allocator's hands) until wait()
 
     def wait(self):
         torch.cuda.current_stream().wait_event(self.event)
+        self.held = None
         return True
 
 
@@ -119,12 +121,14 @@ class SyncBnP2P:
             raise RuntimeError("SyncBnP2P: %d floats exceed the mailbox capacity %d" % (n, self.cap))
         if out.numel() != (self.world * n if mode == 0 else n):
             raise RuntimeError("SyncBnP2P.exchange: wrong output size")
-        self.seq += 1
-        self.exchanges += 1
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(_lib.lib().dcfp_syncbn_p2p_exchange_f32(self.boxes, self.world, self.rank, self.seq, self.cap,
+        # the sequence number advances only for an exchange that was really launched: a launch error on one rank must
+        # not shift its numbering against the peers' for the rest of the run (it is fatal for the group anyway: raised)
+        _lib.check(_lib.lib().dcfp_syncbn_p2p_exchange_f32(self.boxes, self.world, self.rank, self.seq + 1, self.cap,
                                                            _p(local), n, mode, _p(out), run, self.spin,
                                                            _p(self.status), stream), "syncbn_p2p_exchange")
+        self.seq += 1
+        self.exchanges += 1
         return out
 
     def exchange_async(self, local, out, mode):
@@ -138,14 +142,21 @@ class SyncBnP2P:
             self.exchange(local, out, mode)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        return _StreamWork(ev)
+        # `local` and `out` came from the CURRENT stream's allocator pool but are read / written on the side stream: without
+        # this the caching allocator may hand `local`'s block to the next current-stream allocation (the weight gradient
+        # enqueued in between, by design) before the exchange kernel has read it.  c10d does the same for its collectives.
+        local.record_stream(self._side)
+        out.record_stream(self._side)
+        return _StreamWork(ev, (local, out))
 
     def check(self):
-        """Raise if any exchange timed out (blocking read of the status word: call it once per step at most)."""
+        """Raise if any exchange timed out (blocking read of the status word: once per step, next to the step's own
+        host synchronisation - engine.DataParallel.check_exchange(), bench.py and tools/train.py call it there, so that a
+        dead peer stops the job at the first step instead of after ~230 two-minute time-outs per step)."""
         s = int(self.status.item())
         if s != 0:
-            raise RuntimeError("SyncBnP2P: exchange %d gave up waiting for a peer (rank %d of %d)"
-                               % (s, self.rank, self.world))
+            raise RuntimeError("SyncBnP2P: exchange %d gave up waiting for a peer (rank %d of %d; its outputs were "
+                               "poisoned with NaN)" % (s, self.rank, self.world))
 
     def close(self):
         if self.local is None:
@@ -185,6 +196,12 @@ def disable(group=None):
         px = _ACTIVE.pop(g, None)
         if px is not None:
             px.close()
+
+
+def check_all():
+    """Once per step: raise on the first exchange any active group gave up on (no-op without the peer-to-peer exchange)."""
+    for px in list(_ACTIVE.values()):
+        px.check()
 
 
 def finish():

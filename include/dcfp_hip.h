@@ -16,7 +16,9 @@
  *     DCFP_CONV_WINOGRAD (0 direct kernels only / 1 cost model, default / 2 wherever eligible),
  *     DCFP_IGEMM_{DMA,DMA9,DMA8,2D,BK32,PERSIST,P128,TAPSKIP}, DCFP_WGRAD_{DMA,DMA_MIXED,WIDE,LOPSIDED,T192},
  *     DCFP_WINO_VEC, DCFP_WINO_FUSED (0 three-pass Winograd only / 1 fused kernel where it wins, default / 2 wherever it
- *     applies), DCFP_WF_SCALAR_EPI, DCFP_CONV_GEMV (0: 1x1 convs on a 1 x 1 map through the general kernels),
+ *     applies), DCFP_WINO_WGRAD_FUSED (0 batched Winograd weight gradient on the kept transform only / 1 the fused
+ *     weight-gradient kernel where the cost model prefers it, default / 2 wherever it applies and beats the direct
+ *     kernel), DCFP_WINO_WGRAD_RATE (TF the cost model prices that kernel at), DCFP_WF_SCALAR_EPI, DCFP_CONV_GEMV (0: 1x1 convs on a 1 x 1 map through the general kernels),
  *     DCFP_CE_BWD_CELLS (0: the per-output fused upsample + CE backward instead of the cell-organised one) -
  *     kernel / algorithm selection A/B knobs, results are identical up to the documented
  *     fp32 tolerances; changing them after the first call has no effect.  (A thread_local 16-entry cache
@@ -117,7 +119,11 @@ int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass);
  * the same way.  dcfp_conv2d_xform_bytes > 0: the forward call may write that transform (16 x Cin x tiles floats, 4x
  * the size of x) into a caller-owned buffer, and the weight gradient takes it instead of x - a fifth to a quarter of
  * its time - at the price of keeping the buffer alive between the two (the way autograd keeps x).  Same results
- * either way (the same kernels produce the same values).  0: not available for this descriptor. */
+ * either way (the same kernels produce the same values).  0: not available for this descriptor - or not wanted: since
+ * round 4 the weight gradient of most Winograd convs is ONE kernel that transforms x and dy inside the GEMM
+ * (conv_winograd3.hip; dilation 1 / 2 on row-pitched operands with W % 4 == 0, even dilations >= 4 with W even), needs no
+ * kept transform and is what dcfp_conv2d_wgrad_f32_nchw dispatches to; the kept transform remains for the convs that
+ * kernel does not take (dense dilation-1 / 2 operands: conv_deepsup.0 reading layer3's output). */
 size_t dcfp_conv2d_xform_bytes(const DcfpConvDesc* d);
 int dcfp_conv2d_fwd_keep_f32_nchw(const DcfpConvDesc* d, const float* x, const float* w, float* y, int64_t y_nstride,
                                   float* xform_out, size_t xform_bytes,

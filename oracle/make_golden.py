@@ -353,6 +353,57 @@ def eval_golden():
     np.savez_compressed(os.path.join(OUT, "evalmetrics.npz"), **rec)
 
 
+def trajectory_golden(steps=30):
+    """The reference's training iteration (train.py:255-270: zero_grad -> adjust_learning_rate -> forward -> backward ->
+    dcfp_pruning.step -> optimizer.step) run for `steps` iterations on ONE fixed closed-form batch - the reference's own
+    Seg_Model, build_optimizer / adjust_learning_rate (optimizer.py:12-79) and dcfp_pruning (pruners/dcfp_pruner.py:7-26) -
+    in fp32 with 8 / 4 / 2 / 1 threads and without oneDNN (summation order only) and in fp64: the loss curves and the end state.
+    What a longer horizon catches and three steps do not: a stale permuted-weight copy, a momentum slip, a leaked lease."""
+    class A:
+        no_decay = None; optim = "sgd"; momentum = 0.9; learning_rate = 0.01; weight_decay = 5e-4
+    N, H, W = 2, 65, 65
+    rec = {"meta": np.array([N, H, W, steps]), "lr0": np.float64(A.learning_rate), "max_iter": np.int64(4000)}
+    # fp32 variants of the SAME reference code that differ in summation order only - thread counts, and oneDNN switched off
+    # (ATen's native conv: another algorithm over the same products, which is what a HIP kernel is too) - beside fp64
+    variants = (("32", torch.float32, 8, True), ("32t1", torch.float32, 1, True), ("32t2", torch.float32, 2, True),
+                ("32t4", torch.float32, 4, True), ("32nodnn", torch.float32, 8, False), ("64", torch.float64, 8, True))
+    rec["fp32_variants"] = np.array([v[0] for v in variants if v[1] == torch.float32])
+    for sfx, dtype, threads, dnn in variants:
+        torch.set_num_threads(threads)
+        torch.backends.mkldnn.enabled = dnn
+        torch.manual_seed(0)
+        m = build_ref("deeplabv3", "resnet50", True, dtype)
+        m.train()
+        opt_ = ref_optimizer.build_optimizer(A, m)
+        tp = pruners.dcfp_pruning(m, 0.999)
+        x = fill.closed_form_input(N, H, W, dtype)
+        lab = fill.closed_form_labels(N, H, W)
+        losses, lrs = [], []
+        for it in range(steps):
+            opt_.zero_grad()
+            lrs.append(ref_optimizer.adjust_learning_rate(opt_, A.learning_rate, it, 4000, 0.9, -1))
+            loss = m(x, lab, deepsup=True)["loss"]
+            loss.backward()
+            tp.step(m)
+            opt_.step()
+            losses.append(float(loss.item()))
+        rec["loss" + sfx] = np.array(losses, dtype=np.float64)
+        rec["lr" + sfx] = np.array(lrs, dtype=np.float64)
+        eic = tp.get_eic()["eic"]
+        rec["eic_names"] = np.array(list(eic.keys()))
+        rec["eic" + sfx] = torch.cat([v.reshape(-1).float() for v in eic.values()]).numpy()
+        sd = m.state_dict()
+        for k in ("backbone.conv1.0.weight", "last_conv.6.bias", "backbone.layer2.1.bn2.weight", "backbone.bn1.running_var"):
+            rec["w:" + k + ":" + sfx] = sd[k].float().numpy()
+        # every parameter's L2 norm after the last step (a fixture stays small; norms catch a frozen or exploding tensor)
+        rec["param_names"] = np.array([k for k, _ in m.named_parameters()])
+        rec["wnorm" + sfx] = np.array([float(p_.detach().double().norm()) for _, p_ in m.named_parameters()])
+        print("trajectory", sfx, "loss", losses[0], "->", losses[-1], "min", min(losses))
+    torch.set_num_threads(8)
+    torch.backends.mkldnn.enabled = True
+    np.savez_compressed(os.path.join(OUT, "trajectory_v3_r50_2x65x65.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -379,3 +430,5 @@ if __name__ == "__main__":
         gsrl_golden()
     if "eval" in which:          # added in round 3 (leaves the other fixtures untouched)
         eval_golden()
+    if "trajectory" in which:    # added in round 4 (likewise)
+        trajectory_golden()

@@ -46,9 +46,14 @@ def _child(rank, world, out_path):
     # fill of the oracle tests is deliberately not used here: its many exactly-tied / near-zero pre-activations flip
     # ReLU masks under 1e-7 perturbations, which turns summation-order noise into percent-level
     # gradient differences and would hide what this test is after.
+    # DCFP_DDP2_CASE=r101: DeepLabv3-R101 with 2 x 3 x 512 x 1024 per rank - 64 x 128 feature maps: the fused Winograd kernels,
+    # the 256 x 256 LDS-DMA tiles and 2048-channel SyncBN rows of the headline config (the default case's 17 x 33 maps reach
+    # none of them); the fp64 oracle is not run at that size (tests/test_fullsize_gpu.py holds the single-process step to it)
+    big = os.environ.get("DCFP_DDP2_CASE") == "r101"
+    backbone, HH, WW = ("resnet101", 512, 1024) if big else ("resnet50", 129, 257)
     gen = torch.Generator().manual_seed(11)
-    X = torch.randn(4, 3, 129, 257, generator=gen).to(dev)
-    L = torch.randint(0, 19, (4, 129, 257), generator=gen).to(dev)
+    X = torch.randn(4, 3, HH, WW, generator=gen).to(dev)
+    L = torch.randint(0, 19, (4, HH, WW), generator=gen).to(dev)
     if os.environ.get("DCFP_DDP2_CLOSED_FORM"):
         X = fill.closed_form_input(4, 129, 257).to(dev)
         L = fill.closed_form_labels(4, 129, 257).to(dev)
@@ -56,7 +61,7 @@ def _child(rank, world, out_path):
 
     def run(ddp):
         torch.manual_seed(5)                       # default (kaiming) conv init, the same for every run and rank
-        m = networks.deeplabv3.Seg_Model(backbone="resnet50", backbone_para=dict(bb), num_classes=19, align_corner=True,
+        m = networks.deeplabv3.Seg_Model(backbone=backbone, backbone_para=dict(bb), num_classes=19, align_corner=True,
                                          criterion=build_criterions("ce", DS(), {"ds_weight": 0.4}), deepsup=True)
         sd = {k: v.clone() for k, v in m.state_dict().items()}
         for k, v in sd.items():                    # non-trivial BN affine parameters and conv weights at init scale
@@ -137,6 +142,21 @@ def _child(rank, world, out_path):
 
     def rel(a, b):
         return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    if big:
+        cat = lambda d: torch.cat([d[k].reshape(-1).double() for k in full[1]])
+        r1 = {k: rel(ddp[4][k], full[4][k]) for k in full[4]}
+        r1w = max(r1, key=r1.get)
+        per = {k: rel(ddp[1][k], full[1][k]) for k in full[1]}
+        pw = max(per, key=per.get)
+        with open(out_path, "w") as f:
+            json.dump({"ranks_state_equal": bool(torch.equal(both[0], both[1])),
+                       "ranks_grad_equal": bool(torch.equal(gboth[0], gboth[1])),
+                       "loss_full": full[0], "loss_ddp": ddp[0], "p2p_exchanges": n_p2p,
+                       "grad_vs_full_global": rel(cat(ddp[1]), cat(full[1])), "grad_vs_full_worst": [pw, per[pw]],
+                       "running_after_step1_worst": [r1w, r1[r1w]],
+                       "nbt": [int(ddp[3]["backbone.bn1.num_batches_tracked"]), int(full[3]["backbone.bn1.num_batches_tracked"])],
+                       "n_params": len(full[1])}, f)
+        return
     # the truth: one fp64 CPU step of the oracle on the full batch
     cfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
     tr = CpuTrainer(full[5], cfg, lr=1e-3, dtype=torch.float64)
@@ -214,3 +234,21 @@ def test_two_ranks_match_the_full_batch_and_each_other(cuda, tmp_path):
 if __name__ == "__main__" and "--child" in sys.argv:
     i = sys.argv.index("--child")
     _child(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3])
+
+
+@pytest.mark.parametrize("p2p", ["0", "1"])
+def test_two_ranks_r101_at_real_map_sizes(cuda, tmp_path, p2p):
+    """The two-rank step at the headline config's feature-map size (DeepLabv3-R101, each rank 2 x 3 x 512 x 1024), with the
+    SyncBN statistics exchanged by the collectives (p2p = 0) and by the peer-to-peer kernel (1): the ranks leave two
+    optimizer steps with the same bits (gradients, weights, running statistics, EIC), the averaged loss and the pooled
+    running statistics are those of the single-process batch of 4, and the averaged gradient is the single-process
+    gradient up to the fp32 summation-order noise of a 100-layer net (App. D: 1e-2 ... 7e-2 per tensor at this size)."""
+    rec = _run_pair(str(tmp_path / "r101.json"), DCFP_DDP2_CASE="r101", DCFP_SYNCBN_P2P=p2p)
+    print("DDP2-R101", json.dumps(rec))
+    assert rec["ranks_state_equal"] and rec["ranks_grad_equal"]
+    assert (rec["p2p_exchanges"] >= 2 * 2 * 100) == (p2p == "1"), rec["p2p_exchanges"]
+    assert abs(rec["loss_ddp"][0] - rec["loss_full"][0]) <= 2e-6 * abs(rec["loss_full"][0]), rec
+    assert abs(rec["loss_ddp"][1] - rec["loss_full"][1]) <= 2e-3 * abs(rec["loss_full"][1]), rec   # after one SGD step
+    assert rec["running_after_step1_worst"][1] < 2e-4, rec              # pooled statistics = full-batch statistics
+    assert rec["grad_vs_full_global"] < 0.15 and rec["grad_vs_full_worst"][1] < 0.5, rec
+    assert rec["nbt"] == [2, 2] and rec["n_params"] > 300

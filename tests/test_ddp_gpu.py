@@ -1,7 +1,8 @@
 """The data-parallel code path on ONE MI355X: a world-size-1 RCCL group with the SyncBN exchange forced on
 (DCFP_FORCE_SYNCBN=1) and Engine.data_parallel's wrapper (gradient arena + chunked all-reduce) must give
 the SAME BITS as the plain single-process path - loss, every parameter gradient, the EIC vector, the BN
-running statistics - on DeepLabv3-R50 2x3x129x257 (engine.py:63-68, train.py:259-268).  At world size 1
+running statistics - on DeepLabv3-R50 2x3x129x257 and on BASELINE config 3 itself, DeepLabv3-R101 4x3x1024x2048
+(engine.py:63-68, train.py:259-268).  At world size 1
 every collective is the identity, so any difference is a bug in the exchange plumbing (pooled-statistics
 kernel, device-side count, asynchronous sums, arena views), which is exactly what N > 1 runs on top of.
 Runs in a child process: it creates a process group and flips a process-wide switch."""
@@ -35,13 +36,26 @@ def _child():
         no_decay = "bn"; optim = "sgd"; momentum = 0.9; learning_rate = 1e-3; weight_decay = 5e-4
     dev = torch.device("cuda:0")
     bb = {"os": 8, "mg_unit": [1, 2, 4], "inplanes": 128, "pretrained": False}
-    x = fill.closed_form_input(2, 129, 257).to(dev)
-    lab = fill.closed_form_labels(2, 129, 257).to(dev)
+    full = os.environ.get("DCFP_DDP_CASE") == "config3"
+    if full:     # BASELINE config 3: DeepLabv3-R101, 4x3x1024x2048 - the 256 x 256 LDS-DMA tiles, the fused Winograd kernels,
+        # split-K weight gradients writing into the gradient arena, 2048-channel SyncBN rows (bench.py's inputs)
+        backbone = "resnet101"
+        g = torch.Generator().manual_seed(12345)
+        x = torch.randn(4, 3, 1024, 2048, generator=g).to(dev)
+        lab = torch.randint(0, 19, (4, 1024, 2048), generator=g)
+        lab[torch.rand(lab.shape, generator=g) < 0.05] = 255
+        lab = lab.to(dev)
+    else:
+        backbone = "resnet50"
+        x = fill.closed_form_input(2, 129, 257).to(dev)
+        lab = fill.closed_form_labels(2, 129, 257).to(dev)
 
     def run(ddp):
-        m = networks.deeplabv3.Seg_Model(backbone="resnet50", backbone_para=dict(bb), num_classes=19, align_corner=True,
+        torch.manual_seed(12345)
+        m = networks.deeplabv3.Seg_Model(backbone=backbone, backbone_para=dict(bb), num_classes=19, align_corner=True,
                                          criterion=build_criterions("ce", DS(), {"ds_weight": 0.4}), deepsup=True)
-        m.load_state_dict(fill.closed_form_state(m.state_dict()))
+        if not full:
+            m.load_state_dict(fill.closed_form_state(m.state_dict()))
         m.conv_deepsup[3].p = 0.0
         m = m.to(dev).train()
         optimizer = opt.build_optimizer(A, m)
@@ -77,6 +91,11 @@ def _child():
         info["groups"] = [len(g["params"]) for g in optimizer.param_groups]
         bufs = {k: v.detach().clone() for k, v in m.state_dict().items()}
         info["table_rebuilds"] = optimizer.table_rebuilds
+        info["peak_GiB"] = torch.cuda.max_memory_allocated() / 2**30
+        del model, m, optimizer, tp, loss, red
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         return losses, grads, eic, bufs, info
 
     plain = run(False)
@@ -93,8 +112,9 @@ def _child():
     print("DDP_RESULT " + json.dumps(out))
 
 
-def test_syncbn_ddp_path_bit_identical_to_plain(cuda):
-    env = dict(os.environ)
+@pytest.mark.parametrize("case", ["r50_129x257", "config3"])
+def test_syncbn_ddp_path_bit_identical_to_plain(cuda, case):
+    env = dict(os.environ, DCFP_DDP_CASE=case)
     env.pop("DCFP_FORCE_SYNCBN", None)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True,
                        text=True, timeout=900)

@@ -19,6 +19,7 @@ import torch
 
 from oracle import fill, model as omodel
 from oracle.train_step import CpuTrainer
+from _parity import check_per_tensor
 
 pytestmark = pytest.mark.gpu
 WINO = os.environ.get("DCFP_CONV_WINOGRAD", "1") != "0"
@@ -43,7 +44,7 @@ def _build(backbone, device, closed_form=True):
     return m.to(device).train()
 
 
-def _iteration_vs_oracle(backbone, cuda):
+def _iteration_vs_oracle(backbone, cuda, capsys):
     from dcfp_amd import pruners
     N, H, W = 2, 512, 1024
     m = _build(backbone, cuda)
@@ -61,24 +62,23 @@ def _iteration_vs_oracle(backbone, cuda):
     closs, outs, lowres = cpu.step(x, lab, update=False)
     assert abs(loss.item() - closs) <= 2e-5 * max(1.0, abs(closs)), (loss.item(), closs)
 
-    # acceptance as SURVEY.md App. D item 1 states it: error against an fp64 run of the oracle, bounded by 3x the fp32
-    # oracle's own error against that run - per tensor, a tensor whose own fp32 error happens to be tiny being held to the
-    # oracle's worst tensor (R50 at this size: 2e-2; R101, twice as deep: 8e-2 - ReLU masks flip on near-zero
-    # pre-activations, App. D) rather than to a fixed floor
+    # acceptance as SURVEY.md App. D item 1 states it, PER TENSOR: error against an fp64 run of the oracle, bounded by
+    # max(5e-2, 3x the fp32 oracle's own error on THAT tensor against that run) - tests/_parity.py (the only tensors held
+    # to the oracle's worst tensor instead are the three in front of the N-sample BatchNorm aspp.global_avg_pool.2)
     cpu64 = CpuTrainer(sd0, cfg, r=0.999, dtype=torch.float64)
-    cpu64.step(x.double(), lab, update=False)
+    _, outs64, _ = cpu64.step(x.double(), lab, update=False)          # (its forward also serves the logits check below)
     params = dict(m.named_parameters())
     g32, g64 = cpu.params(), cpu64.params()
-    rows = []
+    names, mine, ref = [], [], []
     for k in g64:
         b = g64[k].grad
-        mine = ((params[k].grad.double().cpu() - b).norm() / (b.norm() + 1e-30)).item()
-        ref = ((g32[k].grad.double() - b).norm() / (b.norm() + 1e-30)).item()
-        rows.append((mine, ref, k))
-    noise = max(r[1] for r in rows)
-    bad = sorted(((mi / (3 * max(rf, noise)), mi, rf, k) for mi, rf, k in rows if mi > 3 * max(rf, noise)), reverse=True)
-    assert not bad, (noise, bad[:5])
-    assert noise < 0.2, noise                  # (the oracle itself is meaningful at this size)
+        names.append(k)
+        mine.append(((params[k].grad.double().cpu() - b).norm() / (b.norm() + 1e-30)).item())
+        ref.append(((g32[k].grad.double() - b).norm() / (b.norm() + 1e-30)).item())
+    dump = os.environ.get("DCFP_DUMP_GRAD_ROWS")
+    check_per_tensor(mine, ref, names, f"{backbone} 2x512x1024 gradients", capsys,
+                     dump and os.path.join(dump, f"grad_rows_{backbone}.json"))
+    assert max(ref) < 0.2, max(ref)                  # (the oracle itself is meaningful at this size)
     # the EIC statistic the pruner consumes
     mine = torch.cat([tp.get_eic()["eic"][n].reshape(-1) for n in cpu.scored]).double().cpu().numpy()
     e32 = np.concatenate([np.asarray(cpu.eic[n], dtype=np.float64).reshape(-1) for n in cpu.scored])
@@ -86,16 +86,13 @@ def _iteration_vs_oracle(backbone, cuda):
     rel = np.linalg.norm(mine - e64) / np.linalg.norm(e64)
     ref_rel = np.linalg.norm(e32 - e64) / np.linalg.norm(e64)
     assert rel <= 3 * ref_rel, (rel, ref_rel)
-    # logits of the same (train-mode) forward: low-resolution heads, before the 8x upsample
+    # logits of the same (train-mode) forward on a fresh model (the step above moved the running statistics, which a
+    # train-mode forward does not read): error against the fp64 oracle forward bounded by 3x the fp32 oracle's own
     m2 = _build(backbone, cuda)
     with torch.no_grad():
         outs2 = m2(x.to(cuda), None, deepsup=True)
-    # acceptance as SURVEY.md App. D item 1 states it: error against an fp64 run of the oracle, bounded by
-    # 3x the fp32 oracle's own error against that run (fp32-vs-fp32 differences are both runs' rounding)
-    with torch.no_grad():
-        outs64, _, _ = omodel.seg_forward(omodel.clone_state(sd0, torch.float64, requires_grad=False),
-                                          x.double(), cfg, None, True, None)
     for mine_o, ref32, ref64 in zip(outs2, outs, outs64):
+        ref64 = ref64.detach()
         err = (mine_o.double().cpu() - ref64).abs().max().item()
         ref_err = (ref32.detach().double() - ref64).abs().max().item()
         assert err <= max(1e-3, 3 * ref_err), (err, ref_err, ref64.abs().max().item())
@@ -104,11 +101,11 @@ def _iteration_vs_oracle(backbone, cuda):
         assert rel <= max(1e-4, 3 * ref_rel), (rel, ref_rel)
 
 
-def test_config2_iteration_vs_oracle(cuda):
-    _iteration_vs_oracle("resnet50", cuda)
+def test_config2_iteration_vs_oracle(cuda, capsys):
+    _iteration_vs_oracle("resnet50", cuda, capsys)
 
 
-def test_r101_iteration_vs_oracle_at_real_map_sizes(cuda):
+def test_r101_iteration_vs_oracle_at_real_map_sizes(cuda, capsys):
     """DeepLabv3-R101 at 2x3x512x1024 (64 x 128 feature maps): the 23 layer3 blocks, the multi-grid layer4
     (dilation 4 / 8 / 16, networks/backbone/resnet.py:124-141) and the ASPP branches (dilation 12 / 24 / 36,
     networks/tools/aspp.py:40-47) run through the kernels the headline config uses - Winograd with its 2d x 2d
@@ -123,7 +120,7 @@ def test_r101_iteration_vs_oracle_at_real_map_sizes(cuda):
             desc = ops._desc((2, cin, 64, 128), (cout, cin, 3, 3), 1, dil, dil)
             seen[tag] = [ops.conv_kernel_name(desc, k) for k in (_lib.CONV_FWD, _lib.CONV_DGRAD, _lib.CONV_WGRAD)]
         assert all(any(n.startswith("winograd_f2x2_3x3") for n in names) for names in seen.values()), seen
-    _iteration_vs_oracle("resnet101", cuda)
+    _iteration_vs_oracle("resnet101", cuda, capsys)
 
 
 @pytest.fixture(scope="module")
@@ -231,6 +228,7 @@ SLICE_SHAPES = [
     ((4, 1024, 128, 256, 512, 3, 1, 1, 1), ("igemm2_dma_kernel<9,true>", "wgrad_dma_kernel<9,true>")),    # conv_deepsup.0
     ((4, 512, 128, 256, 512, 3, 1, 16, 16), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # layer4.2 conv2 (mg_unit 4)
     ((4, 512, 128, 256, 512, 3, 1, 8, 8), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),    # layer4.1 conv2
+    ((4, 2048, 128, 256, 256, 3, 1, 36, 36), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # ASPP d36: dgrad stays direct with Winograd on (dead kernel rows)
     ((4, 64, 512, 1024, 128, 3, 1, 1, 1), (None, None)),                                                  # stem
     ((4, 128, 256, 512, 128, 3, 2, 1, 1), (None, None)),                                                  # layer2.0 conv2 (stride 2)
     ((4, 256, 256, 512, 512, 1, 2, 0, 1), (None, None)),                                                  # layer2.0 downsample (stride 2)

@@ -155,3 +155,28 @@ def test_eval_oracle_vs_reference_golden():
     assert miou == float(g["miou"]) and np.array_equal(iou, g["iou"])
     p, r = em.precision_recall(cm)
     assert p == float(g["precision"]) and r == float(g["recall"])
+
+
+def test_oracle_trainer_follows_the_reference_trajectory():
+    """oracle/train_step.py (the checker of the multi-step GPU tests and bench.py's CPU baseline) against the REFERENCE's
+    own loop pieces (tests/golden/trajectory_v3_r50_2x65x65.npz: Seg_Model + build_optimizer + adjust_learning_rate +
+    dcfp_pruning for 30 steps): first loss to 1e-6 relative, the next steps inside the band of the reference's own
+    fp32 / 1-thread / fp64 spread (the summation order of this host's thread count is a fourth variant)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _parity import trajectory_band
+    from oracle.train_step import CpuTrainer
+    from oracle import scoring
+    g = np.load(os.path.join(G, "trajectory_v3_r50_2x65x65.npz"))
+    N, H, W, _ = [int(v) for v in g["meta"]]
+    l64, band = trajectory_band(g)
+    cfg = omodel.Cfg(model="deeplabv3", backbone="resnet50", align_corner=True)
+    x, lab = fill.closed_form_input(N, H, W), fill.closed_form_labels(N, H, W)
+    tr = CpuTrainer(product_state("deeplabv3", "resnet50", True)[1], cfg, lr=float(g["lr0"]), momentum=0.9, weight_decay=5e-4, r=0.999)
+    for it in range(6):
+        tr.lr = scoring.lr_poly(float(g["lr0"]), it, int(g["max_iter"]), 0.9)
+        assert abs(tr.lr - g["lr64"][it]) <= 1e-15
+        loss, _, _ = tr.step(x, lab)
+        assert abs(loss - l64[it]) <= band[it], (it, loss, l64[it], band[it])
+        if it == 0:
+            assert abs(loss - g["loss32"][0]) <= 1e-6 * abs(loss)

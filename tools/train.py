@@ -124,7 +124,10 @@ def main(argv=None):
             optimizer.zero_grad()
             lr = adjust_learning_rate(optimizer, args.learning_rate, it, args.num_steps, args.power, args.warmup)
             loss = model(images, labels, deepsup=args.deepsup)
-            assert loss["loss"] == loss["loss"]
+            if not bool(loss["loss"] == loss["loss"]):     # (train.py:260-261 asserts this - a host sync per step, as there)
+                from dcfp_amd import syncbn_p2p
+                syncbn_p2p.check_all()                     # a SyncBN exchange that gave up on a peer poisons with NaN: say so
+                raise AssertionError("loss is NaN")
             reduce_loss = engine.all_reduce_tensor(loss["loss"])
             loss["loss"].backward()
             if train_pruning is not None:
