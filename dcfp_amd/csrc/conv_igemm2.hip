@@ -1189,6 +1189,10 @@ int dcfp_igemm2_run(const float* in, long long in_nstride, const float* w, int s
         p.tile2d = (fits && !pitched && T == 9 && ((off0 | offstep) & 3) != 0 && Ho == Hi && Wo == Wi) ? t2d : 0;
     }
     p.tapskip = 0;      // decided below, once the tiling is known
+    {
+        static const int nt = [] { const char* e = getenv("DCFP_IGEMM_NT"); return e ? atoi(e) : 0; }();
+        p.nt_store = nt;
+    }
     p.tiles_per_img = (p.P + (d8 ? 256 : c.bn) - 1) / (d8 ? 256 : c.bn);
     p.Hc = p.Wc = p.tiles_per_phase = p.zfold = 0;
     if (sd > 1) {     // strided dgrad: sd*sd phases, each tiled over its own coarse grid

@@ -403,9 +403,14 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
                     constexpr int row = TM * ((r & 3) + 8 * (r >> 2)) + i;
                     f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
                     if constexpr (ACC) v += old[r];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
-                        __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                        o_rsrc, voff + (unsigned)row * P4, 0, 0);   // row offset in the VGPR: see igemm2_kernel
+                    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u4;
+                    if (ACC || p.nt_store == 0)       // (block-uniform; the cache-policy bits are an immediate)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v),
+                            o_rsrc, voff + (unsigned)row * P4, 0, 0);   // row offset in the VGPR: see igemm2_kernel
+                    else if (p.nt_store == 1)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), o_rsrc, voff + (unsigned)row * P4, 0, 2);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), o_rsrc, voff + (unsigned)row * P4, 0, 18);
                 });
                 if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);
             });

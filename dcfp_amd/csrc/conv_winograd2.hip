@@ -250,17 +250,22 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
             af[fb] = *reinterpret_cast<const f32x4*>(As + g * 512);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) bf[fb][kk] = Bs[(g * FBK + 2 * kk) * 64];
-            if constexpr (PROD && g < 4) {
-                row_transform_one<DM, g>(R[rb], q);
-                // pin the row here: left alone, hipcc sinks these subtractions to the column transforms of slots 4..15,
-                // which keeps R alive under the loads of slots 8..15 (register copies behind fresh loads = stalls)
-#pragma unroll
-                for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) asm volatile("" : "+v"(q[g][c]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][0], bf[fb ^ 1][0], acc[pg], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            // ONE burst of vector / scalar ALU work per slot, in front of its MFMAs (round 4, tools/micro/mfma_shadow.hip: with one
+            // wave per SIMD every VALU / SALU instruction costs ~4.5 cycles of matrix-pipe time, every switch MFMA -> ALU -> MFMA
+            // ~8 more, and an LDS write right behind the instruction that produced its data ~20; LDS reads / writes by themselves
+            // are free): the row transform (slots 0..3), this component's column transform, the LDS-DMA piece's M0 set-up.  The
+            // LDS write of the component follows two MFMAs later.
+            f32x2 o = {0.f, 0.f};
             if constexpr (PROD) {
+                if constexpr (g < 4) {
+                    row_transform_one<DM, g>(R[rb], q);
+                    // pin the row here: left alone, hipcc sinks these subtractions to the column transforms of slots 4..15,
+                    // which keeps R alive under the loads of slots 8..15 (register copies behind fresh loads = stalls)
+#pragma unroll
+                    for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) asm volatile("" : "+v"(q[g][c]));
+                }
+                o = col_transform<DM, g>(q);
+                asm volatile("" : "+v"(o));
                 if constexpr (g < 8) {        // piece g of this wave's 8 LDS-DMA pieces of the next A image
                     const unsigned piece = (unsigned)(wid_s * 8 + g);
                     const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((cur ^ 1) * 2 * FSTAGE) * 4u + piece * 1024u);
@@ -271,10 +276,13 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
                                  :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][0], bf[fb ^ 1][0], acc[pg], 0, 0, 0);
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][1], bf[fb ^ 1][1], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PROD) {
-                const f32x2 o = produce(g_, cur ^ 1);
+                float* bs = smem + (cur ^ 1) * 2 * FSTAGE + FSTAGE + (g * FBK + ch) * 64 + 2 * l31;
+                *reinterpret_cast<f32x2*>(bs) = o;
                 if constexpr (SIDE) {
                     if constexpr (g < 8) okeep[g] = o;
                     else if (st) {
@@ -283,6 +291,7 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][2], bf[fb ^ 1][2], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PROD && g >= 8) {

@@ -12,8 +12,8 @@
 //   * every thread loads the 4x4 x-patches of ONE tile pair of ONE input channel (as conv_winograd2.hip does) AND the 2x2
 //     dy-tiles of the same pair of ONE output channel, transforms both in registers (64 + 24 additions) and writes
 //     16 + 16 eight-byte values into the two LDS images the MFMA fragments are read from: V and Y never exist;
-//   * both images are [xi][channel 64][tile 8]: a lane's four K-pairs of a component are ONE ds_read_b128 for A and one
-//     for B (the forward kernel needs four ds_read_b32 for its B operand);
+//   * both images keep a channel's tiles contiguous: a lane's four K-pairs of a component are ONE ds_read_b128 for A and
+//     one for B (the forward kernel needs four ds_read_b32 for its B operand);
 //   * the sign of a dy component, (-1)^[i == 3] (-1)^[j == 3] (A = [1 0; 1 1; 1 -1; 0 -1]), is applied to the accumulator
 //     in the epilogue instead of to 16 values per K-step;
 //   * split-K over the tiles in a fixed order: slabs [split][xi][M][C], summed and transformed G^T dU G by ONE small
@@ -28,7 +28,17 @@
 namespace {
 
 constexpr int GBK = 8;                      // tiles per K-step
-constexpr int GSTAGE = 16 * 64 * GBK;       // floats of one operand of one LDS stage (32 KB)
+// LDS image of one operand of one stage, per component: [half (2: wave row / column)][k half (2)][channel 32][4 tiles], the
+// k halves 144 floats apart (128 + 16: half a bank row) -
+//   * a lane's fragment (channel l31, tiles 4 lhi .. 4 lhi + 3) is 16 bytes and consecutive lanes read consecutive 16-byte
+//     pieces: conflict-free ds_read_b128 for both halves of the wave;
+//   * a producer thread (channel, tile pair j) writes 8 bytes at k half j >> 1: the 16 lanes of a ds_write_b64 group cover 4
+//     channels x 4 pairs = banks 0..15 (j < 2) and 16..31 (j >= 2) - conflict-free because of the 16-float skew.
+// (A plain [channel 64][tile 8] image made both accesses 2-way conflicts: profiles/r04_wino_wgrad_fused_sq_pmc.txt.)
+constexpr int GKH = 144;                    // floats between the k halves
+constexpr int GHALF = 2 * GKH;              // floats of one 32-channel half of a component
+constexpr int GCOMP = 2 * GHALF;            // floats of one component (576)
+constexpr int GSTAGE = 16 * GCOMP;          // floats of one operand of one LDS stage (36 KB)
 constexpr unsigned kSat = 0xffffffffu;
 
 struct WinoWgParams {
@@ -170,7 +180,7 @@ __device__ __forceinline__ f32x2 dy_component(const float (&U)[4][4]) {
 template <int DM, bool RAGGED>
 __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgParams p) {
     constexpr int NX = PatchCfg<DM>::NV, NY = DyCfg<DM>::NY, NT = 2 + NX + NY;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][A 8192 | B 8192]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][A GSTAGE | B GSTAGE]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     // linear block L = (split * cblocks + cb) * mblocks + mb, cut into 8 contiguous runs, one per XCD (blocks b, b + 8, ...
@@ -253,26 +263,24 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgPa
         else if constexpr (I < 2 + NX) load_one<DM, I - 2>(x_rsrc, vx, 0u, R[b]);
         else load_dy_one<DM, I - 2 - NX>(y_rsrc, vy, D[b]);
     };
-    const int pw = 2 * tid;                                        // (cl * 8 + 2 j): this thread's slot in a component's image
+    const int pw = (cl >> 5) * GHALF + (j >> 1) * GKH + (cl & 31) * 4 + 2 * (j & 1);     // this thread's slot in a component's image
     auto produce_x = [&](auto xi_, int buf) {
         constexpr int XI = decltype(xi_)::value;
         const f32x2 o = col_transform<DM, XI>(q);
-        *reinterpret_cast<f32x2*>(smem + buf * 2 * GSTAGE + GSTAGE + XI * 512 + pw) = o;
+        *reinterpret_cast<f32x2*>(smem + buf * 2 * GSTAGE + GSTAGE + XI * GCOMP + pw) = o;
     };
     auto produce_y = [&](auto xi_, int buf) {
         constexpr int XI = decltype(xi_)::value;
         const f32x2 o = dy_component<DM, XI>(U);
-        *reinterpret_cast<f32x2*>(smem + buf * 2 * GSTAGE + XI * 512 + pw) = o;
+        *reinterpret_cast<f32x2*>(smem + buf * 2 * GSTAGE + XI * GCOMP + pw) = o;
     };
     auto dy_rows = [&](auto g_, const float (&Dd)[2][4]) {        // row g of A g (unsigned), pinned into its slot
         constexpr int g = decltype(g_)::value;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if constexpr (g == 0) U[0][c] = Dd[0][c];
-            if constexpr (g == 1) U[1][c] = Dd[0][c] + Dd[1][c];
-            if constexpr (g == 2) U[2][c] = Dd[0][c] - Dd[1][c];
-            if constexpr (g == 3) U[3][c] = Dd[1][c];
-            asm volatile("" : "+v"(U[g][c]));
+            if constexpr (g == 0) { U[0][c] = Dd[0][c]; U[3][c] = Dd[1][c]; }      // (plain copies: the register allocator's business)
+            if constexpr (g == 1) { U[1][c] = Dd[0][c] + Dd[1][c]; asm volatile("" : "+v"(U[1][c])); }
+            if constexpr (g == 2) { U[2][c] = Dd[0][c] - Dd[1][c]; asm volatile("" : "+v"(U[2][c])); }
         }
     };
     auto retire = [&]() {
@@ -303,8 +311,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgPa
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int a_lane = (wm * 32 + l31) * 8 + 4 * lhi;
-    const int b_lane = (wn * 32 + l31) * 8 + 4 * lhi;
+    const int a_lane = wm * GHALF + lhi * GKH + l31 * 4;
+    const int b_lane = wn * GHALF + lhi * GKH + l31 * 4;
     // ---- K loop.  A K-step is 16 slots, one per component g: slot g reads the fragments of component g (consumed one
     // slot later) and issues the 4 MFMAs of component g - 1; slot 0 issues those of the previous step's component 15.
     // Beside the MFMAs a slot carries its share of building K-step kt + 1 into the other LDS stage: slots 0..3 one row of
@@ -322,24 +330,39 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_fused_kernel(const WinoWgPa
         static_for<0, 16>([&](auto g_) {
             constexpr int g = decltype(g_)::value;
             constexpr int fb = g & 1, pg = (g + 15) & 15;
-            af[fb] = *reinterpret_cast<const f32x4*>(As + g * 512);
-            bf[fb] = *reinterpret_cast<const f32x4*>(Bs + g * 512);
-            if constexpr (PROD && g < 4) {
-                row_transform_one<DM, g>(R[rb], q);
+            af[fb] = *reinterpret_cast<const f32x4*>(As + g * GCOMP);
+            bf[fb] = *reinterpret_cast<const f32x4*>(Bs + g * GCOMP);
+            // ONE burst of vector-ALU work per slot, in front of its MFMAs (tools/micro/mfma_shadow.hip: with one wave per SIMD
+            // every VALU / SALU instruction costs ~4.5 cycles of matrix-pipe time and every switch MFMA -> VALU -> MFMA ~8 more;
+            // LDS reads and writes cost nothing - unless a write sits right behind the instruction that produced its data,
+            // ~20 cycles): the row transforms (slots 0..3), this component's two column transforms, and in slot 7 the buffer
+            // offsets of K-step kt + 3.  The LDS writes follow two MFMAs later, the loads one MFMA after them.
+            f32x2 ox = {0.f, 0.f}, oy = {0.f, 0.f};
+            if constexpr (PROD) {
+                if constexpr (g < 4) {
+                    row_transform_one<DM, g>(R[rb], q);
+                    // pin the row here: left alone, hipcc sinks these subtractions to the column transforms of later slots,
+                    // which keeps R alive under the loads of slots 8..15 (conv_winograd2.hip)
 #pragma unroll
-                for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) asm volatile("" : "+v"(q[g][c]));
-                dy_rows(g_, D[rb]);
+                    for (int c = 0; c < PatchCfg<DM>::NCOL; ++c) asm volatile("" : "+v"(q[g][c]));
+                    dy_rows(g_, D[rb]);
+                }
+                oy = dy_component<DM, g>(U);
+                ox = col_transform<DM, g>(q);
+                asm volatile("" : "+v"(ox), "+v"(oy));      // (computed here, not sunk to the stores)
+                if constexpr (g == 7) make_offsets();
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][0], bf[fb ^ 1][0], acc[pg], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROD) produce_y(g_, rb);
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][1], bf[fb ^ 1][1], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROD) produce_x(g_, rb);
+            if constexpr (PROD) {
+                *reinterpret_cast<f32x2*>(smem + rb * 2 * GSTAGE + g * GCOMP + pw) = oy;
+                *reinterpret_cast<f32x2*>(smem + rb * 2 * GSTAGE + GSTAGE + g * GCOMP + pw) = ox;
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[pg] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fb ^ 1][2], bf[fb ^ 1][2], acc[pg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROD && g == 7) make_offsets();
             if constexpr (PROD && g >= 8) {
                 constexpr int lo = (g - 8) * NT / 8, hi = (g - 7) * NT / 8;
                 static_for<lo, hi>([&](auto i_) { vmem_op(i_, std::integral_constant<int, rb>{}, k_entry); });

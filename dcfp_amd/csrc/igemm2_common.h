@@ -28,6 +28,8 @@ struct Igemm2Params {
     const unsigned long long* fan_mask;   // fan_mask is set (layout of dcfp_bn_apply_relu_mask_f32), fan_src laid out as out
     long long wp_nstride;   // igemm2_dma1p_kernel: floats between the weight copies of consecutive images (0: shared) - the
                             // batched GEMM of conv_winograd.hip, where "image" xi has its own transformed filter
+    int nt_store;       // igemm2_dma1p_kernel, plain epilogue: cache policy of the output stores (A/B knob DCFP_IGEMM_NT: 0 default,
+                        // 1 nt, 2 nt + sc1) - the conv output is next read by a BatchNorm pass streaming it from HBM
     int tapskip;        // 9-tap LDS-DMA kernels: K-steps of kernel rows that lie wholly in the padding for a tile are skipped
     float* stat_part;   // nullable: per-(pixel-tile, wave-column) row statistics [slot][M][2] = (mean, M2)
     // igemm2_dma1p_kernel with fan_src (nullable as a group): the fan-in's OUTPUT is the gradient `g_out` arriving at the
