@@ -145,15 +145,15 @@ static int wino_kind(const DcfpConvDesc* d, int pass) {
         const double mpad = (double)((M + 255) / 256 * 256) / M;      // the GEMM's tiles are 256 (128) rows: ragged M pays for the padding
         t_wino = nominal * f_wino * mpad / rate + t_in + t_out + 20e-6;
     }
-    if (fused && (!three || M % 256 != 0)) {
-        // (on the 256 grid the three-pass model decides - and dcfp_wino_run takes the fused kernel where it wins; off it -
-        //  narrow layers, pruned widths - the fused kernel pads M to 64 instead of 256)
-        // the fused kernel: 115 TF in its K loop, about four K-steps' worth of prologue + epilogue per block (measured
-        // executed rates, profiles/r03_wino_fused_ab.txt: 77 TF at 64 input channels, 96 at 128, 110 at 256, 118 at 1024);
-        // blocks are 64 output channels
+    if (fused) {
+        // the fused kernel (what dcfp_wino_run takes wherever it applies, except where the forward must leave V behind):
+        // 125 TF of executed MFMA work in its K loop since round 4 (one ALU burst per slot), about four K-steps' worth of
+        // prologue + epilogue per block (measured executed rates, profiles/r04_wino_fused_burst_ab.txt: 87 TF at 64 input
+        // channels, 110 at 256, 122 at 512, 118 at 2048 with 16 % tile padding); blocks are 64 output channels - off the 256
+        // grid (narrow layers, pruned widths) it pads M to 64 instead of 256
         const double nk = (double)((Ck + 15) / 16 * 2);
         const double mpad = (double)((M + 63) / 64 * 64) / M;
-        const double t_f = nominal * f_wino * mpad / (115e12 * nk / (nk + 4.0)) + 10e-6;
+        const double t_f = nominal * f_wino * mpad / (125e12 * nk / (nk + 4.0)) + 10e-6;
         if (t_f < t_wino) t_wino = t_f;
     }
     if (!(t_wino < 0.97 * t_direct)) return 0;

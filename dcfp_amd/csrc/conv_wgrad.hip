@@ -1033,7 +1033,7 @@ static int wino_wgrad_kind(const DcfpConvDesc* d) {
     }
     if (fused) {
         const double pad64 = (double)((d->Cout + 63) / 64 * 64) / d->Cout * (double)((d->Cin + 63) / 64 * 64) / d->Cin;
-        t_f = nominal * f * pad64 / wino_wgrad_fused_rate() + 15e-6;
+        t_f = nominal * f * pad64 / wino_wgrad_fused_rate() + 40e-6;      // (+ table kernel, split-K reduce + transform kernel)
     }
     if (fused && (t_f <= t_b || wino_wgrad_fused_forced())) return t_f < 0.97 * t_direct ? 2 : 0;
     return t_b < 0.97 * t_direct ? 1 : 0;

@@ -479,15 +479,16 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
     // The fused kernel (conv_winograd2.hip) where it measures faster than the three passes (same-box A/B,
-    // profiles/r03_wino_fused_ab.txt): everywhere except (a) a forward that must leave V behind for the weight gradient
-    // with more than 256 input channels - the three-pass path has V anyway, the fused kernel writes it on the side at
-    // HBM speed (1...5 GB) - and (b) an accumulating dgrad with >= 1024 output channels (short K, the read-modify-write
-    // of the output dominates).  Where the three passes do not apply at all (fewer than 129 / 128 channels: the narrow
+    // profiles/r03_wino_fused_ab.txt, profiles/r04_wino_fused_burst_ab.txt): everywhere except a forward that must leave V
+    // behind for a BATCHED weight gradient with more than 256 input channels - the three-pass path has V anyway, the fused
+    // kernel writes it on the side at HBM speed (1...5 GB).  (Round 3 also kept accumulating dgrads with >= 1024 output
+    // channels - the ASPP branches - on the three passes: a wash then, 0.3 ms per launch for the fused kernel since its
+    // K loop got faster in round 4.)  Where the three passes do not apply at all (fewer than 129 / 128 channels: the narrow
     // layers of the stem, layer1, layer2 and of pruned models) the fused kernel is the Winograd path.
     // DCFP_WINO_FUSED=2 takes it wherever it applies (tests).
     static const int fused_mode = [] { const char* e = getenv("DCFP_WINO_FUSED"); return e ? atoi(e) : 1; }();
     const bool three_ok = dcfp_wino_ok(N, H, W, d, M, Ck);
-    const bool fused_wins = fused_mode == 2 || !three_ok || (!(xform_out && Ck > 256) && !(accumulate && M >= 1024));
+    const bool fused_wins = fused_mode == 2 || !three_ok || !(xform_out && Ck > 256);
     if (fused_wins && dcfp_wino_fused_ok(N, H, W, d, M, Ck, in_nstride, in_pitch) &&
         workspace_bytes >= dcfp_wino_fused_workspace_bytes(N, H, W, d, M, Ck)) {
         if (stat_part && (!dcfp_wino_stat_slots(N, H, W, d) || accumulate)) return DCFP_E_UNSUPPORTED;
