@@ -92,53 +92,64 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
         return t;
     };
 
-    // ---- loader state: the tile whose K-steps are being copied, and the next K-step of it
+    // ---- loader state: the tile whose K-steps are being copied, and the next K-step of it.
+    // Everything a copy needs beyond its lane offset is a RUNNING wave-uniform byte offset, stepped by one scalar add per
+    // K-step (round 4: with one wave per SIMD every scalar / vector ALU instruction of the loop costs ~4.5 cycles of
+    // matrix-pipe time - tools/micro/mfma_shadow.hip - and recomputing (k-row) x (row pitch) per piece was ~70 of them per
+    // K-step): a_run / b_run = offset of k-row 4w of the K-step in the weight copy / the activation image.
     int ld_tile = next_valid(blockIdx.x), ld_cb = 0;
-    unsigned ld_as = 0, ld_boff4 = 0;
+    unsigned ld_boff4 = 0;
+    unsigned a_run = 0, b_run = 0;
     u32x4 ld_bdesc = a_desc;
+    const unsigned a_row = (unsigned)p.Mpad * 4u, b_row = (unsigned)HiWi * 4u;           // one k-row
+    const unsigned a_kstep = (unsigned)(BK * p.Mpad) * 4u, b_kstep = (unsigned)(BK * HiWi) * 4u;
+    const unsigned lds_a_w = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)(4 * wid_s * BM) * 4u);
+    const unsigned lds_b_w = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)(4 * wid_s * BN) * 4u);
     auto ld_set_tile = [&]() {
         int nt, mt;
         decode(ld_tile, nt, mt);
         const int img = nt / p.tiles_per_img;
         const int p0 = (nt - img * p.tiles_per_img) * BN;
-        ld_as = (unsigned)(mt * BM + (WPI ? img * (int)p.wp_nstride : 0)) * 4u;
+        a_run = __builtin_amdgcn_readfirstlane((unsigned)(mt * BM + (WPI ? img * (int)p.wp_nstride : 0)) * 4u +
+                                               (unsigned)(4 * wid_s) * a_row);
+        b_run = __builtin_amdgcn_readfirstlane((unsigned)(4 * wid_s) * b_row);
         ld_bdesc = make_desc(p.in + (long long)img * p.in_nstride, (unsigned)(p.Ck * HiWi) * 4u);
         const int pp = p0 + 4 * lane;                 // P % 4 == 0: a quad is inside or outside as a whole
         ld_boff4 = pp < p.P ? (unsigned)pp * 4u : kOob;
     };
     // one of the 8 copies of a K-step: piece 2q = k-row 4w+q of A, piece 2q+1 = the same row of B
-    auto issue_piece = [&](int buf, auto piece_) {
+    auto issue_piece = [&](unsigned abuf, unsigned bbuf, auto piece_) {      // abuf / bbuf: LDS byte address of the wave's rows in the stage
         constexpr int piece = decltype(piece_)::value;
         constexpr int q = piece >> 1;
         if constexpr ((piece & 1) == 0) {
             if constexpr (TM == 4) {
-                const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)((ld_cb * BK + 4 * wid_s + q) * p.Mpad) * 4u);
-                const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid_s + q) * BM) * 4u);
+                const unsigned a_s = a_run + (unsigned)q * a_row;
                 const unsigned av = lane16;
                 const u32x4 ad = a_desc;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+                // (M0 = LDS address of the row, written by the add itself: stage base + a literal)
+                asm volatile("s_add_i32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(abuf), "v"(av), "s"(ad), "s"(a_s), "i"(q * BM * 4) : "memory", "m0", "scc");
             } else if constexpr (q < 2) {
                 // a 128-float k-row is 512 bytes: one instruction copies rows 4w + 2q (lanes 0..31) and 4w + 2q + 1
-                const unsigned a_s = __builtin_amdgcn_readfirstlane(ld_as + (unsigned)((ld_cb * BK + 4 * wid_s + 2 * q) * p.Mpad) * 4u);
-                const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BK + 4 * wid_s + 2 * q) * BM) * 4u);
+                const unsigned a_s = a_run + (unsigned)(2 * q) * a_row;
                 const unsigned av = a2_voff;
                 const u32x4 ad = a_desc;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(la), "v"(av), "s"(ad), "s"(a_s) : "memory", "m0");
+                asm volatile("s_add_i32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(abuf), "v"(av), "s"(ad), "s"(a_s), "i"(2 * q * BM * 4) : "memory", "m0", "scc");
             }
         } else {
             // channel-row offset in the VGPR offset: the descriptor's bound must see it (rows past Ck -> zeros)
-            const unsigned b_cb = (unsigned)__builtin_amdgcn_readfirstlane((ld_cb * BK + 4 * wid_s + q) * HiWi) * 4u;
+            const unsigned b_cb = b_run + (unsigned)q * b_row;
             const unsigned b_s = 0;
-            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)((buf * BK + 4 * wid_s + q) * BN) * 4u);
             const unsigned bv = ld_boff4 + b_cb;
             const u32x4 bd = ld_bdesc;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(lb), "v"(bv), "s"(bd), "s"(b_s) : "memory", "m0");
+            asm volatile("s_add_i32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(bbuf), "v"(bv), "s"(bd), "s"(b_s), "i"(q * BN * 4) : "memory", "m0", "scc");
         }
     };
     auto ld_advance = [&]() {        // after the 8 pieces of a K-step: step the loader (and cross the tile boundary)
+        a_run += a_kstep;
+        b_run += b_kstep;
         if (++ld_cb == nk) {
             ld_cb = 0;
             ld_tile = next_valid(ld_tile + gridDim.x);
@@ -146,7 +157,9 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
         }
     };
     auto issue = [&](int buf) {      // copy K-step ld_cb of tile ld_tile into LDS buffer `buf`, then step the loader
-        static_for<0, 8>([&](auto piece_) { issue_piece(buf, piece_); });
+        // LDS byte address of this wave's first row in the stage (the pieces add their row as a literal)
+        const unsigned abuf = lds_a_w + (buf ? (unsigned)(BK * BM) * 4u : 0u), bbuf = lds_b_w + (buf ? (unsigned)(BK * BN) * 4u : 0u);
+        static_for<0, 8>([&](auto piece_) { issue_piece(abuf, bbuf, piece_); });
         ld_advance();
     };
     auto retire = [&]() {   // every copy (and every older store) done, every fragment read done, then the barrier

@@ -602,7 +602,49 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         c_ow += BK;
         if (c_ow >= p.Wo) { c_ow = 0; if (++c_oh >= p.Ho) { c_oh = 0; ++c_im; } }
     };
+    // ---- 1x1 convs (TAPS == 1: no tap shift, no padding - every copy of a K-step reads 16 consecutive pixels of rows that
+    // exist): the whole address of a copy is a lane constant plus ONE running wave-uniform byte offset per operand, stepped
+    // by scalar adds (row / image wrap included), and the 8 copies of a K-step are issued as one burst.  Round 4: with one
+    // wave per SIMD every scalar / vector ALU instruction of the loop costs ~4.5 cycles of matrix-pipe time
+    // (tools/micro/mfma_shadow.hip) and the general path below spends ~150 of them per K-step on coordinates it re-derives
+    // per piece; same copies, same order, same bits.
+    unsigned b1_voff[4] = {0u, 0u, 0u, 0u};
+    unsigned a1_run = 0, b1_run = 0;
+    const unsigned a1_row = (unsigned)(p.dy_pitch - p.Wo) * 4u, b1_row = (unsigned)(p.x_pitch - p.W) * 4u;
+    const unsigned a1_img = (unsigned)((int)p.dy_nstride - p.Ho * p.dy_pitch) * 4u, b1_img = (unsigned)((int)p.x_nstride - p.H * p.x_pitch) * 4u;
+    const unsigned lds_a_w = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)(64 * wid * BK) * 4u);
+    const unsigned lds_b_w = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)(64 * wid * BK) * 4u);
+    if constexpr (TAPS == 1 && !MIXED) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1_voff[q] = (unsigned)(bq_c[q] + 4 * gq + padx) * 4u;
+        a1_run = __builtin_amdgcn_readfirstlane((unsigned)(c_oh * p.dy_pitch + c_ow) * 4u);
+        b1_run = __builtin_amdgcn_readfirstlane((unsigned)(c_oh * p.x_pitch + c_ow) * 4u);
+    }
+    auto issue1 = [&](int buf) {
+        const unsigned abuf = lds_a_w + (buf ? (unsigned)(BM * BK) * 4u : 0u), bbuf = lds_b_w + (buf ? (unsigned)(BN * BK) * 4u : 0u);
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            const unsigned av = a_voff[q], base = abuf, run = a1_run;
+            const u32x4 ad = a_desc;
+            asm volatile("s_add_i32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(base), "v"(av), "s"(ad), "s"(run), "i"(16 * q * BK * 4) : "memory", "m0", "scc");
+        });
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            const unsigned bv = b1_voff[q], base = bbuf, run = b1_run;
+            const u32x4 bd = b_desc;
+            asm volatile("s_add_i32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(base), "v"(bv), "s"(bd), "s"(run), "i"(16 * q * BK * 4) : "memory", "m0", "scc");
+        });
+        // step to the next 16 pixels: same row, next row, or next image
+        c_ow += BK; a1_run += BK * 4u; b1_run += BK * 4u;
+        if (c_ow >= p.Wo) {
+            c_ow = 0; a1_run += a1_row; b1_run += b1_row;
+            if (++c_oh >= p.Ho) { c_oh = 0; a1_run += a1_img; b1_run += b1_img; }
+        }
+    };
     auto issue = [&](int buf) {
+        if constexpr (TAPS == 1 && !MIXED) { issue1(buf); return; }
         static_for<0, 4>([&](auto q_) { issue_a(buf, q_); });
         static_for<0, 4>([&](auto q_) { issue_b(buf, q_); });
         advance();
@@ -663,7 +705,12 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
                             bf[1][j2] = *reinterpret_cast<const f32x4*>(b + j2 * 32 * BK + f1);
                         });
                     }
-                    if constexpr (s == 0 && (n & 1) == 1) {      // piece n / 2 of the next step's copies
+                    if constexpr (TAPS == 1 && !MIXED) {
+                        if constexpr (s == 0 && n == 1) {           // all 8 copies of the next step: one burst, one branch
+                            if (more) issue1(cur ^ 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if constexpr (s == 0 && (n & 1) == 1) {      // piece n / 2 of the next step's copies
                         if (more) {
                             constexpr int piece = n / 2;
                             if constexpr (piece < 4) issue_a(cur ^ 1, std::integral_constant<int, piece>{});

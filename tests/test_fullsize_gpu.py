@@ -229,7 +229,7 @@ SLICE_SHAPES = [
     ((4, 512, 128, 256, 512, 3, 1, 16, 16), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # layer4.2 conv2 (mg_unit 4)
     ((4, 512, 128, 256, 512, 3, 1, 8, 8), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),    # layer4.1 conv2
     ((4, 2048, 128, 256, 256, 3, 1, 36, 36), ("igemm2_dma_kernel<9,false>", "wgrad_dma_kernel<9,false>")),  # ASPP d36: dgrad stays direct with Winograd on (dead kernel rows)
-    ((4, 64, 512, 1024, 128, 3, 1, 1, 1), (None, None)),                                                  # stem
+    ((4, 64, 512, 1024, 128, 3, 1, 1, 1), (None, None)),                                                  # stem (dense operands here: direct kernels)
     ((4, 128, 256, 512, 128, 3, 2, 1, 1), (None, None)),                                                  # layer2.0 conv2 (stride 2)
     ((4, 256, 256, 512, 512, 1, 2, 0, 1), (None, None)),                                                  # layer2.0 downsample (stride 2)
 ]
@@ -280,6 +280,53 @@ def test_config3_dgrad_wgrad_vs_fp64_slice(cuda, shape, kernels):
     assert rel(dx[:, ci], rdx) < max(tol, 1e-5), rel(dx[:, ci], rdx)
     assert rel(dxa[:, ci], rdx + seed[:, ci].double()) < max(tol, 1e-5)
     assert rel(dw[:, ci], rdw) < 2e-5, rel(dw[:, ci], rdw)      # N*Ho*Wo-long reduction, split-K in a fixed order
+
+
+# the config-3 launch geometries of the FUSED Winograd weight gradient (conv_winograd3.hip: split-K factor, blocks per XCD, the
+# tile table of a 4-image batch) on the operands the model hands it - row-pitched for dilation 1 / 2, dense for >= 4 - against
+# fp64 on a slice of input channels, with the routing asserted (WINO: DCFP_CONV_WINOGRAD != 0)
+WGF_SHAPES = [(4, 256, 128, 256, 256, 2),      # layer3 conv2 (x 23)
+              (4, 512, 128, 256, 512, 4),      # layer4.0 conv2
+              (4, 2048, 128, 256, 256, 12),    # ASPP d12: 16 % padded tiles
+              (4, 2048, 128, 256, 256, 36),    # ASPP d36: 27 %
+              (4, 512, 128, 256, 256, 1),      # last_conv.0
+              (4, 64, 512, 1024, 64, 1),       # stem conv1.3: ONE 64 x 64 block, 256 splits
+              (4, 64, 512, 1024, 128, 1),      # stem conv1.6
+              (4, 128, 128, 256, 128, 1)]      # layer2 conv2
+
+
+@pytest.mark.parametrize("shape", WGF_SHAPES)
+def test_config3_fused_winograd_wgrad_vs_fp64_slice(cuda, shape):
+    import math
+    import torch.nn.functional as F
+    from dcfp_amd import ops, _lib
+    if not WINO or os.environ.get("DCFP_WINO_WGRAD_FUSED", "1") == "0":
+        pytest.skip("Winograd / fused weight gradient switched off")
+    N, Cin, H, W, Cout, d = shape
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x = (torch.relu(x) + 0.05 * x).to(cuda)
+    dy = (torch.randn(N, Cout, H, W, generator=g) * 1e-2).to(cuda)
+    wshape = (Cout, Cin, 3, 3)
+    pitch = ops.conv_pitch(tuple(x.shape), wshape, 1, d, d)
+    assert (pitch > 0) == (d <= 2)
+    xs, dys = x, dy
+    if pitch:
+        xs = ops.new_pitched(tuple(x.shape), pitch, cuda); xs.copy_(x)
+        dys = ops.new_pitched(tuple(dy.shape), pitch, cuda); dys.copy_(dy)
+    desc = ops._desc(x.shape, wshape, 1, d, d, pitch, pitch)
+    name = ops.conv_kernel_name(desc, _lib.CONV_WGRAD)
+    assert name.startswith("winograd_f2x2_3x3 wgrad fused"), name
+    assert _lib.lib().dcfp_conv2d_xform_bytes(ops.C.byref(desc)) == 0        # nothing kept from the forward pass for it
+    dw = ops.conv2d_wgrad(dys, xs, wshape, 1, d, d)[0]
+    torch.cuda.synchronize()
+    nci = min(Cin, 8)
+    ci = slice(Cin - nci, Cin)
+    w64 = torch.zeros(Cout, nci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[:, ci].double().cpu(), w64, None, 1, d, d).backward(dy.double().cpu())
+    ref = w64.grad.to(cuda)
+    rel = ((dw[:, ci].double() - ref).norm() / ref.norm()).item()
+    assert rel < 2e-5, rel          # (the stated tolerance of the conv tests for weight gradients; measured 0.7e-6 ... 4e-6)
 
 
 # ---------------------------------------------------------------- config 5 at full size: the slim R101

@@ -199,8 +199,8 @@ def test_narrow_layers_on_the_fused_winograd_kernel(cuda, shape):
     # applies to these widths) where the operands allow it - pitched rows of a multiple of 4 pixels for dilation 1 / 2, any
     # even width for dilation >= 4 - and the cost model prefers it; never the batched path (needs >= 128 channels)
     assert names[2].startswith("winograd_f2x2_3x3 wgrad fused") or not names[2].startswith("winograd"), names
-    if os.environ.get("DCFP_WINO_WGRAD_FUSED", "1") != "0" and d == 1:      # (the stem / layer1 / layer2 shapes: the model's)
-        assert names[2].startswith("winograd_f2x2_3x3 wgrad fused"), names
+    # (which of the two the cost model takes at these small sizes is its business - tests/test_wino_wgrad_fused_gpu.py holds
+    #  the kernel itself to fp64, tests/test_fullsize_gpu.py asserts it on the model's own stem / layer1 / layer2 geometries)
     wd = w.to(cuda)
     y, st = ops.conv2d_fwd(xs, wd, None, 1, d, d, want_stats=True)
     dx = ops.conv2d_dgrad(dys, wd, tuple(x.shape), 1, d, d)
