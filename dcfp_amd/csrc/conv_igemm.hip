@@ -67,6 +67,10 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
                   float* stat_part = nullptr, const float* scale = nullptr, const float* shift = nullptr,
                   const float* residual = nullptr, int relu = 0);
 long long dcfp_wino_stat_slots(int N, int H, int W, int d);
+bool dcfp_stem_shape(const DcfpConvDesc* d);                                                            // conv_stem.hip
+int dcfp_stem_fwd(const DcfpConvDesc* d, const float* x, const float* w, const float* bias, float* y, long long y_nstride,
+                  hipStream_t stream, float* stat_part = nullptr);
+long long dcfp_stem_stat_slots(const DcfpConvDesc* d, const float* y, long long y_nstride);
 bool dcfp_gemv_shape(const DcfpConvDesc* d);                                                            // conv_gemv.hip
 int dcfp_gemv_fwd(const DcfpConvDesc* d, const float* x, const float* w, const float* bias, float* y, long long y_nstride,
                   hipStream_t stream);
@@ -193,6 +197,7 @@ extern "C" int dcfp_conv2d_kernel_name(const DcfpConvDesc* d, int pass, char* bu
     if (!buf || buf_len <= 0) return DCFP_E_BADDESC;
     if (dcfp_gemv_shape(d)) return snprintf(buf, buf_len, "gemv_1x1_map_kernel");
     if (pass == DCFP_CONV_WGRAD) return dcfp_wgrad_kernel_name(d, buf, buf_len);
+    if (pass == DCFP_CONV_FWD && dcfp_stem_shape(d)) return snprintf(buf, buf_len, "stem_fwd_kernel");
     if (const int wk = wino_kind(d, pass))
         return wk == 1 ? snprintf(buf, buf_len, "winograd_f2x2_3x3 (igemm2_dma1p_kernel<false,true>)")
                        : snprintf(buf, buf_len, "winograd_f2x2_3x3 fused (wino_fused_kernel)");
@@ -279,6 +284,7 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     const int T = d->KH * d->KW;
     if (d->x_pitch && d->x_pitch != d->W && math_bf16x3()) return DCFP_E_UNSUPPORTED;
     if (dcfp_gemv_shape(d)) return dcfp_gemv_fwd(d, x, w, bias, y, y_nstride, dcfp_s(stream));
+    if (dcfp_stem_shape(d)) return dcfp_stem_fwd(d, x, w, bias, y, y_nstride, dcfp_s(stream));     // Cin = 3, stride 2: conv_stem.hip
     if (!bias && wino_pass(d, DCFP_CONV_FWD))
         return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T,
                              0, y, y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout,
@@ -299,6 +305,7 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
 // dcfp_bn_stats_from_partials_f32).  slots == 0: this shape / math mode has no fused statistics.
 extern "C" int64_t dcfp_conv2d_fwd_stat_slots(const DcfpConvDesc* d, const float* y, int64_t y_nstride) {
     if (check_desc(d) != DCFP_OK) return 0;
+    if (dcfp_stem_shape(d)) return dcfp_stem_stat_slots(d, y, y_nstride);
     if (wino_pass(d, DCFP_CONV_FWD))                // (the output transform emits them where every tile is interior)
         return (y_nstride % 4 == 0 && dcfp_aligned16(y)) ? dcfp_wino_stat_slots(d->N, d->H, d->W, d->dil) : 0;
     if (igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1)) return 0;
@@ -315,6 +322,7 @@ extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float
     if (!x || !w || !y || !stat_partials) return DCFP_E_BADDESC;
     if (dcfp_conv2d_fwd_stat_slots(d, y, y_nstride) <= 0) return DCFP_E_UNSUPPORTED;
     const int T = d->KH * d->KW;
+    if (dcfp_stem_shape(d)) return dcfp_stem_fwd(d, x, w, nullptr, y, y_nstride, dcfp_s(stream), stat_partials);
     if (wino_pass(d, DCFP_CONV_FWD))
         return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T, 0, y,
                              y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, d->H, d->W,

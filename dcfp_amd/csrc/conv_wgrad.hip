@@ -915,6 +915,10 @@ int launch_taps(const WgradParams& p, const Plan& pl, hipStream_t stream) {
 }  // namespace
 
 bool dcfp_gemv_shape(const DcfpConvDesc* d);     // conv_gemv.hip
+bool dcfp_stem_shape(const DcfpConvDesc* d);     // conv_stem.hip
+size_t dcfp_stem_wgrad_workspace_bytes(const DcfpConvDesc* d);
+int dcfp_stem_wgrad(const DcfpConvDesc* d, const float* dy, long long dy_nstride, const float* x, float* dw, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream);
 int dcfp_gemv_wgrad(const DcfpConvDesc* d, const float* dy, long long dy_nstride, const float* x, float* dw, hipStream_t stream);
 
 // pitched operands: the LDS-DMA kernels and the register-staged wgrad2_kernel (not the bf16x3 split kernel), 3x3 with
@@ -1001,6 +1005,7 @@ static bool wino_wgrad_pass(const DcfpConvDesc* d);
 static int wino_wgrad_kind(const DcfpConvDesc* d);
 
 int dcfp_wgrad_kernel_name(const DcfpConvDesc* d, char* buf, int buf_len) {
+    if (dcfp_stem_shape(d)) return snprintf(buf, buf_len, "stem_wgrad_kernel");
     if (const int wk = wino_wgrad_kind(d))
         return wk == 2 ? snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad fused (wino_wgrad_fused_kernel)")
                        : snprintf(buf, buf_len, "winograd_f2x2_3x3 wgrad (wgrad_dma_kernel<1,false,false,true>)");
@@ -1101,6 +1106,7 @@ size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass);
 extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
     if (pass == DCFP_CONV_FWD || pass == DCFP_CONV_DGRAD) return dcfp_conv2d_fwd_dgrad_workspace_bytes_(d, pass);
     if (pass != DCFP_CONV_WGRAD || check_desc(d) != DCFP_OK) return 0;
+    if (dcfp_stem_shape(d)) return dcfp_stem_wgrad_workspace_bytes(d);
     if (const int wk = wino_wgrad_kind(d)) {
         // (kind 2 can fall back to the batched path at run time - a dy slice whose image stride breaks the 31-bit offsets -
         //  so the query covers both where both apply)
@@ -1123,6 +1129,8 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (!dy || !x || !dw) return DCFP_E_BADDESC;
     if (dcfp_gemv_shape(d) && !db)      // a 1x1 conv on a 1 x 1 map (ASPP image pool): conv_gemv.hip
         return dcfp_gemv_wgrad(d, dy, dy_nstride, x, dw, dcfp_s(stream));
+    if (dcfp_stem_shape(d) && !db)      // Cin = 3, stride 2 (backbone.conv1.0): conv_stem.hip
+        return dcfp_stem_wgrad(d, dy, dy_nstride, x, dw, workspace, workspace_bytes, dcfp_s(stream));
     if (const int wk = wino_wgrad_kind(d)) {
         const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout, xp = d->x_pitch ? d->x_pitch : d->W;
         const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;

@@ -4,6 +4,7 @@ dilations, padding smaller and larger than the dilation reach, accumulate-dgrad 
 convolutions.  Complements the fixed cases of test_ops_gpu.py (reference layer shapes) and
 test_conv_large_gpu.py (256 x 256-tile kernels)."""
 import math
+import os
 import random
 
 import pytest
@@ -122,3 +123,51 @@ def test_random_conv(cuda, case):
     assert rel(dx, x64.grad) < max(tol, 1e-5), ("dgrad", case, rel(dx, x64.grad))
     assert rel(dxa, x64.grad + seed.double()) < max(tol, 1e-5), ("dgrad+acc", case)
     assert rel(dw, w64.grad) < 2e-5, ("wgrad", case, rel(dw, w64.grad))
+
+
+# the Cin = 3 stride-2 stem conv (networks/backbone/resnet.py:88-90) on its own kernels (dcfp_amd/csrc/conv_stem.hip: no LDS,
+# operands straight into the MFMA lane layout): forward (+ bias), weight gradient (wave slabs reduced in a fixed order) against
+# fp64; image borders (row / column -1, odd heights: the last patch row outside), widths that leave a partly filled wave
+# (a wave takes 128 output pixels), fewer than 3 input channels, a dy that is a batch-strided view, and the BatchNorm
+# statistics epilogue (output widths that are multiples of 128) against the statistics kernel on the same output
+STEM = [(2, 3, 64, 128), (1, 3, 51, 64), (3, 2, 33, 192), (2, 3, 128, 512), (4, 1, 16, 64), (1, 3, 24, 1280)]
+
+
+@pytest.mark.parametrize("case", STEM)
+def test_stem_conv_kernels(cuda, case):
+    import torch
+    import torch.nn.functional as F
+    from dcfp_amd import ops, _lib
+    N, Cin, H, W = case
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(64, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(64, generator=g)
+    desc = ops._desc(x.shape, w.shape, 2, 1, 1)
+    on = os.environ.get("DCFP_CONV_STEM", "1") != "0"
+    assert (ops.conv_kernel_name(desc, _lib.CONV_FWD) == "stem_fwd_kernel") == on
+    assert (ops.conv_kernel_name(desc, _lib.CONV_WGRAD) == "stem_wgrad_kernel") == on
+    xd, wd = x.to(cuda), w.to(cuda)
+    y = ops.conv2d_fwd(xd, wd, None, 2, 1, 1)
+    yb = ops.conv2d_fwd(xd, wd, b.to(cuda), 2, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 1, 1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    assert ((yb.cpu().double() - (ref + b.double().view(1, -1, 1, 1))).abs().max() / ref.abs().max()).item() < 2e-6
+    r = ops.conv2d_fwd(xd, wd, None, 2, 1, 1, want_stats=True)
+    ys, st = r if isinstance(r, tuple) else (r, None)
+    assert torch.equal(ys, y)
+    assert (st is not None) == (on and ref.shape[3] % 128 == 0), (st is None, ref.shape)
+    if st is not None:
+        m_ref, v_ref = ops.bn_stats(y)
+        assert float((st[0] - m_ref).abs().max() / m_ref.abs().max()) < 2e-5
+        assert float(((st[1] - v_ref).abs() / v_ref).max()) < 2e-5
+    dy = torch.randn(ref.shape, generator=g)
+    dw = ops.conv2d_wgrad(dy.to(cuda), xd, tuple(w.shape), 2, 1, 1)[0]
+    dw2 = ops.conv2d_wgrad(dy.to(cuda), xd, tuple(w.shape), 2, 1, 1)[0]
+    refw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 2, 1, 1)
+    assert torch.equal(dw, dw2)                                    # fixed summation order
+    assert ((dw.cpu().double() - refw).norm() / refw.norm()).item() < 2e-5
+    wide = torch.randn(N, 96, *ref.shape[2:], generator=g).to(cuda)      # dy as a channel slice: its own image stride
+    wide[:, 16:80] = dy.to(cuda)
+    assert torch.equal(ops.conv2d_wgrad(wide[:, 16:80], xd, tuple(w.shape), 2, 1, 1)[0], dw)
