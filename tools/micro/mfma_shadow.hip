@@ -102,6 +102,65 @@ void run(float* out, const float* gsrc) {
            MODE, NV * 64, PK ? "v_pk_add" : "v_add   ", NV * G, NR * 16, NW * 16, best, flops / best / 1e9, cyc);
 }
 
+// Two waves per SIMD (512 threads, 8 accumulator tiles each): does one wave's ALU burst overlap the other wave's MFMAs?
+// Per wave and "K-step": 32 MFMAs + NV v_add_f32 per MFMA in bursts of 4 x NV (one burst per slot of 4 MFMAs).
+// PH: the odd wave of a SIMD starts half a period (BURST / 2 MFMAs) out of phase; BURST = MFMAs between two ALU bursts
+template <int NV, int BURST = 4, bool PH = false>
+__global__ void __launch_bounds__(512, 1) k2(float* out, int iters, float a0, float b0) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int tid = threadIdx.x;
+    float a = a0 + tid, b = b0 - tid;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = a0 + i;
+    if (PH && ((tid >> 6) & 4)) {       // waves 4..7 share the SIMDs of waves 0..3
+#pragma unroll
+        for (int m = 0; m < BURST / 2; ++m) acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 7], 0, 0, 0);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            if ((m % BURST) == 0) {
+#pragma unroll
+                for (int i = 0; i < BURST * NV; ++i) { v[i & 7] += b; asm volatile("" : "+v"(v[i & 7])); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    if (s == 12345.678f) out[tid] = s;
+}
+template <int NV, int BURST = 4, bool PH = false>
+void run2(float* out) {
+    const int iters = 4000, blocks = 256;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k2<NV, BURST, PH>), dim3(blocks), dim3(512), 0, 0, out, iters, 0.f, 0.f);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flops = (double)blocks * 8 * iters * 32.0 * 4096.0;
+    printf("2 waves/SIMD%s, per wave and 32 MFMAs: %3d v_add in bursts of %2d   %8.3f ms  %6.1f TFLOP/s  %5.1f cycles/MFMA @2.4GHz\n",
+           PH ? " (out of phase)" : "", NV * 32, NV * BURST, best, flops / best / 1e9, best * 1e-3 / (iters * 64.0) * 2.4e9);
+}
+
 int main() {
     float* out; (void)hipMalloc(&out, 4096);
     float* g; (void)hipMalloc(&g, 1024 * 1024 * 4); (void)hipMemset(g, 0, 1024 * 1024 * 4);
@@ -114,5 +173,8 @@ int main() {
     run<0, 1, false, 2, 2, 2>(out, g);      // + 16 global loads per K-step
     run<1, 4, false, 2, 2, 2>(out, g);
     run<0, 1, false, 0, 0, 3>(out, g);      // 256 SALU ops per K-step
+    run2<0>(out); run2<1>(out); run2<2>(out); run2<3>(out); run2<4>(out);
+    run2<2, 8>(out); run2<2, 16>(out); run2<2, 32>(out); run2<3, 8>(out); run2<3, 16>(out);
+    run2<2, 4, true>(out); run2<2, 8, true>(out); run2<2, 16, true>(out); run2<3, 8, true>(out); run2<3, 16, true>(out);
     return 0;
 }
