@@ -1112,8 +1112,14 @@ extern "C" size_t dcfp_conv2d_workspace_bytes(const DcfpConvDesc* d, int pass) {
         //  so the query covers both where both apply)
         const size_t b1 = dcfp_wino_wgrad_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin)
                               ? dcfp_wino_wgrad_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) : 0;
-        const size_t b2 = wk == 2 ? dcfp_wino_wgrad_fused_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) : 0;
-        return wk == 2 ? b2 : b1;
+        if (wk == 1) return b1;
+        // kind 2 falls back at run time when the REAL image stride of dy (a channel slice of a wider tensor) breaks the
+        // kernel's 31-bit offsets: to the batched path where that applies, else to the direct kernels - the query covers all
+        const size_t b2 = dcfp_wino_wgrad_fused_workspace_bytes(d->N, d->H, d->W, d->dil, d->Cout, d->Cin);
+        const Plan pl = make_plan(d);
+        const size_t b0 = pl.splits > 1 ? (size_t)pl.splits * d->Cout * d->Cin * d->KH * d->KW * sizeof(float) : 0;
+        const size_t m = b1 > b0 ? b1 : b0;
+        return b2 > m ? b2 : m;
     }
     const Plan pl = make_plan(d);
     if (pl.splits <= 1) return 0;
@@ -1131,13 +1137,18 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         return dcfp_gemv_wgrad(d, dy, dy_nstride, x, dw, dcfp_s(stream));
     if (dcfp_stem_shape(d) && !db)      // Cin = 3, stride 2 (backbone.conv1.0): conv_stem.hip
         return dcfp_stem_wgrad(d, dy, dy_nstride, x, dw, workspace, workspace_bytes, dcfp_s(stream));
-    if (const int wk = wino_wgrad_kind(d)) {
+    int wk = wino_wgrad_kind(d);
+    if (wk == 2) {      // the descriptor-level decision assumed a dense batch stride for dy: check the real one
+        const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout, xp = d->x_pitch ? d->x_pitch : d->W;
+        const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;
+        if (!dcfp_wino_wgrad_fused_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin, (long long)d->Cin * d->H * xp, xp, dyn, dyp))
+            wk = dcfp_wino_wgrad_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin) ? 1 : 0;     // batched Winograd, or the direct kernels below
+    }
+    if (wk) {
         const int dyp = d->dy_pitch ? d->dy_pitch : d->Wout, xp = d->x_pitch ? d->x_pitch : d->W;
         const long long dyn = dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * dyp;
         if (db && dyp != d->Wout) return DCFP_E_UNSUPPORTED;      // (the bias-gradient kernel reads dense rows; nothing launched yet)
         if (wk == 2) {
-            if (!dcfp_wino_wgrad_fused_ok(d->N, d->H, d->W, d->dil, d->Cout, d->Cin, (long long)d->Cin * d->H * xp, xp, dyn, dyp))
-                return DCFP_E_UNSUPPORTED;                        // (a dy slice too far apart for 31-bit offsets)
             rc = dcfp_wino_wgrad_fused_run(dy, dyn, dyp, x, (long long)d->Cin * d->H * xp, xp, dw, d->N, d->Cout, d->Cin, d->H,
                                            d->W, d->dil, workspace, workspace_bytes, dcfp_s(stream));
         } else

@@ -18,7 +18,8 @@
  *     DCFP_WINO_VEC, DCFP_WINO_FUSED (0 three-pass Winograd only / 1 fused kernel where it wins, default / 2 wherever it
  *     applies), DCFP_WINO_WGRAD_FUSED (0 batched Winograd weight gradient on the kept transform only / 1 the fused
  *     weight-gradient kernel where the cost model prefers it, default / 2 wherever it applies and beats the direct
- *     kernel), DCFP_WINO_WGRAD_RATE (TF the cost model prices that kernel at), DCFP_WF_SCALAR_EPI, DCFP_CONV_GEMV (0: 1x1 convs on a 1 x 1 map through the general kernels),
+ *     kernel), DCFP_WINO_WGRAD_RATE (TF the cost model prices that kernel at), DCFP_CONV_STEM (0: the Cin = 3 stem conv
+ *     through the general kernels), DCFP_IGEMM_NT (1 / 2: nt / sc1 output stores of the 1x1 kernel, A/B), DCFP_WF_SCALAR_EPI, DCFP_CONV_GEMV (0: 1x1 convs on a 1 x 1 map through the general kernels),
  *     DCFP_CE_BWD_CELLS (0: the per-output fused upsample + CE backward instead of the cell-organised one) -
  *     kernel / algorithm selection A/B knobs, results are identical up to the documented
  *     fp32 tolerances; changing them after the first call has no effect.  (A thread_local 16-entry cache
