@@ -116,6 +116,14 @@ class Engine(object):
             model = DataParallel(model, n_chunks=n_chunks)
             if syncbn_p2p.wanted() and torch.cuda.is_available():
                 # opt-in (DCFP_SYNCBN_P2P=1): the 230 per-layer SyncBN collectives become single peer-to-peer kernels
+                if dist.get_rank() == 0:
+                    import sys
+                    print("dcfp_amd: DCFP_SYNCBN_P2P=1 - SyncBN statistics through the peer-to-peer exchange kernel.  It is "
+                          "bit-identical to the collectives between processes SHARING one GPU (tests/test_syncbn_p2p_gpu.py, "
+                          "tests/test_ddp2_gpu.py) but has never run across xGMI: its flag / data ordering over the fabric is "
+                          "argued, not observed.  A give-up poisons the statistics with NaN and stops the job at that step "
+                          "(syncbn_p2p.check_all()); compare `comm.syncbn_exposed_ms` with the default RCCL path before relying "
+                          "on it.", file=sys.stderr, flush=True)
                 syncbn_p2p.enable(dist.group.WORLD, torch.device("cuda", torch.cuda.current_device()))
         return model
 
