@@ -998,7 +998,9 @@ class BottleneckFn(torch.autograd.Function):
         # that fan-in's result): bn3's input, the ReLU bit mask and the batch mean.  The record travels on the output
         # tensor; the consumer leaves the partial sums in it and this block's backward picks them up.
         ctx.rec = None
-        if FANIN_BN_SUMS and len(st3) > 4:
+        # (only when a backward pass can follow: a training-mode forward under no_grad builds no graph, and the record on
+        #  its output would keep bn3's input alive for nothing)
+        if FANIN_BN_SUMS and len(st3) > 4 and any(ctx.needs_input_grad):
             ctx.rec = {"c3": c3, "mask": st3[4], "mean": st3[0]}
             out._dcfp_bn3_rec = ctx.rec
         return out

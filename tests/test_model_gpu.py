@@ -547,6 +547,32 @@ def test_fanin_epilogue_bn_sums(cuda):
     b = torch.cat([g1[k].reshape(-1).double() for k in g0])
     assert float((a - b).norm() / a.norm()) < 1e-4          # (wrong sums would be O(1); reordered fp32 sums are ~1e-6)
 
+    # the partial sums are only trusted for the very tensor the fan-in wrote: a gradient that reaches a block's output
+    # through a hook - a new tensor with other values - must send that block's bn3 back to its own reduce kernel, and the
+    # edit must arrive in the parameter gradients (same pointer + same version counter is the only state the sums are trusted in)
+    from dcfp_amd.networks.backbone.resnet import Bottleneck
+
+    def chain(hook):
+        ops.FANIN_RED_USED[0] = 0
+        torch.manual_seed(3)
+        blocks = [Bottleneck(1024, 256, stride=1, dilation=2).to(dev).train() for _ in range(3)]
+        gx = torch.Generator().manual_seed(4)
+        x = torch.randn(2, 1024, 64, 128, generator=gx).to(dev).requires_grad_(True)
+        h = blocks[0](x)
+        if hook is not None:
+            h.register_hook(hook)
+        y = blocks[2](blocks[1](h))
+        y.backward(torch.randn(y.shape, generator=gx).to(dev))
+        torch.cuda.synchronize()
+        return [p.grad.clone() for b in blocks for p in b.parameters()], ops.FANIN_RED_USED[0]
+    plain, used_plain = chain(None)
+    scaled, used_new = chain(lambda gr: gr * 2.0)                  # a NEW tensor arrives at block 0's output
+    assert used_plain == 2 and used_new == 1, (used_plain, used_new)
+    n0p = len(list(Bottleneck(1024, 256).parameters()))
+    for k, (a_, b_) in enumerate(zip(plain, scaled)):
+        want = a_ * 2.0 if k < n0p else a_                           # block 0 sees the doubled gradient, blocks 1 / 2 do not
+        assert float((b_ - want).norm() / want.norm().clamp_min(1e-30)) < 1e-5, k
+
 
 def test_dropped_graph_releases_the_pitched_buffers(cuda, monkeypatch):
     """A grad-enabled forward whose graph never runs backward (validation without no_grad, the NaN guard raising,
