@@ -23,6 +23,19 @@ for kind, key, work, ms in recs:
         k = (kind, key.Cin, key.Cout, key.H, key.W, key.KH, key.stride, key.dil, name)
         a = agg.setdefault(k, [0.0, 0.0, 0]); a[0] += work; a[1] += ms; a[2] += 1
 tot = 0
+if "--all" in sys.argv:      # every (pass, shape) entry of the step with the MFMA work it really issues
+    desc = {}
+    for kind, key, work, ms in recs:
+        if kind in which:
+            desc[(kind, key.Cin, key.Cout, key.H, key.W, key.KH, key.stride, key.dil, ops.conv_kernel_name(key, which[kind]))] = \
+                ops.conv_executed_fraction(key, which[kind])
+    all_ms = 0.0
+    for k, (w, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        all_ms += ms
+        print("%-14s Cin%4d Cout%4d %4dx%4d k%d s%d d%2d  n=%2d  %7.3f ms  %6.1f TF nominal  %6.1f TF executed  %s" % (
+            k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], n, ms, w / (ms * 1e-3) / 1e12, w * desc[k] / (ms * 1e-3) / 1e12, k[8]))
+    print("total %.1f ms" % all_ms)
+    sys.exit(0)
 for k, (w, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     tf = w / (ms * 1e-3) / 1e12
     if tf < 125 and not k[-1].startswith("winograd"):
