@@ -4,11 +4,11 @@
 // K = Cin x 9 = 27: the general implicit-GEMM kernels pad it to their 16-deep K-steps and stage a stride-2 im2col through LDS
 // (0.61 ms forward at 12 TF, 0.36 ms weight gradient at 20 TF for 4 x 3 x 1024 x 2048: profiles/r03_conv_entries_below_125tf.txt)
 // although the conv moves 638 MB for 7.2 GFLOP, i.e. is bound by HBM (0.1 ms).  Here K = 27 (+1 zero) is 14 K-pairs of
-// v_mfma_f32_32x32x2_f32 with NO LDS at all - the operands go from global memory straight into the MFMA's lane layout:
+// v_mfma_f32_32x32x2_f32 without im2col and without workgroup-level staging (a wave parks data only in its own LDS region):
 //   forward   y[co][p] = sum_t w[co][t] x_t[p]:  A = the 64 x 28 weights, held in 28 registers per lane for the whole kernel
-//             (lane = (co % 32, K-pair half)); B = the 28 taps of 32 consecutive output pixels of a row, lane = (pixel, half):
-//             14 dword loads per lane (stride-2 columns: half of every line is used, the other half by the neighbouring tap);
-//             28 MFMAs per 32 pixels; the 32 x 32 result tiles have pixels along the lanes: 128-byte store segments.
+//             (lane = (co % 32, K-pair half)); the other operand = the 28 taps of 32 consecutive output pixels of a row,
+//             lane = (pixel, half), read from the segment's input window that the wave stages once in LDS; 28 MFMAs per 32
+//             pixels; pixels along M, so a lane holds 4 consecutive pixels of a channel: 16-byte stores.
 //   wgrad     dw[co][t] = sum_p dy[co][p] x_t[p]:  K = pixels.  A = dy, lane = (co % 32, pixel half): one 16-byte load covers the
 //             lane's 4 pixels of an 8-pixel group; B = x_t[p], lane = (tap, pixel half): 4 dword loads; 8 MFMAs per 8 pixels.
 //             A wave owns a contiguous run of 8-pixel groups and leaves its 64 x 27 partial in a slab; stem_wgrad_reduce sums
@@ -48,9 +48,18 @@ __device__ __forceinline__ void tap_of(int t, int T, int H, int W, int& off, int
 // layout dcfp_bn_stats_from_partials_f32 merges (part[slot][64][2], slot = linear pixel / 128), combined sub-step by sub-step
 // with Chan's formula in a fixed order.
 constexpr int kStemSeg = 4;
+constexpr int kXRow = 264;                 // staged floats per (channel, kernel row): columns 2 ox0 - 4 ... 2 ox0 + 259
+constexpr int kXPitch = kXRow + 4;         // + 4: the 9 rows start 8 banks apart
+// The taps of a segment's 128 pixels overlap (27 taps per pixel, 2.3 distinct input floats per pixel): the wave stages the
+// segment's input window ONCE - 9 (channel, kernel row) rows of 264 floats, 16-byte loads along the row, 10 per lane - in its
+// own 9.4 KB of LDS and reads the taps from there (a first version loaded every tap from global memory: 56 scattered dword
+// loads per lane and segment, 0.30 ms - the texture path, not HBM, was the limit).  The next segment's loads are in flight
+// while this one computes.
 template <bool STATS>
 __global__ void __launch_bounds__(256) stem_fwd_kernel(const StemParams p) {
+    __shared__ __attribute__((aligned(16))) float xs_all[4][9 * kXPitch];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+    float* xs = xs_all[wid];
     // a wave walks kStemSeg segments of 128 output pixels (the 28 weights per lane are loaded once per wave): segment
     // s = (row, 128-pixel column block), rows = n * Ho + oy
     const int spr = (p.Wo + 127) >> 7;                          // segments per output row
@@ -59,46 +68,56 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const StemParams p) {
     if (seg0 >= nseg) return;                                   // wave-uniform
     // B: weights of output channels l31 and 32 + l31, K-pair j = taps (2j, 2j + 1), this lane holds tap 2j + lhi
     float wb[2][14];
+    int xoff[14];                                               // LDS offset of tap 2j + lhi for pixel 0 of a sub-step
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
         const int t = 2 * j + lhi;
         wb[0][j] = t < p.T ? p.w[l31 * p.T + t] : 0.f;
         wb[1][j] = t < p.T ? p.w[(32 + l31) * p.T + t] : 0.f;
+        const int tt = t < p.T ? t : 0;                         // (a dead tap multiplies a zero weight: any staged value will do)
+        const int rc = tt / 3, kw = tt - rc * 3;                // rc = ci * 3 + kh
+        xoff[j] = rc * kXPitch + 3 + kw + 2 * l31;              // column 2 (ox - ox0) - 1 + kw, window starting at 2 ox0 - 4
     }
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    // per K-pair: tap offset, its kernel row / column (the validity tests depend on the segment and the sub-step)
-    int toff[14], tkw[14], tkh[14];
-    bool tlive[14];
-#pragma unroll
-    for (int j = 0; j < 14; ++j) tap_of(2 * j + lhi, p.T, p.H, p.W, toff[j], tkh[j], tkw[j], tlive[j]);
     const long long plane = (long long)p.Ho * p.Wo;
+    const int nrc = p.Cin * 3, nchunk = nrc * (kXRow / 4);      // 16-byte chunks of a segment's window
+    f32x4 stage[10];
+    auto fetch = [&](long long seg) {                           // this lane's chunks lane, lane + 64, ... of segment `seg`
+        const int rowi = (int)(seg / spr), ox0 = (int)(seg - (long long)rowi * spr) * 128;
+        const int n = rowi / p.Ho, oy = rowi - n * p.Ho;
+        const int img = n * p.Cin * p.H * p.W;                  // (32-bit: the tensor is below 2^31 bytes, dcfp_stem_shape)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int c = lane + 64 * i;
+            const int rc = c / (kXRow / 4), q = c - rc * (kXRow / 4);
+            const int ci = rc / 3, kh = rc - ci * 3;
+            const int h = 2 * oy - 1 + kh, col = 2 * ox0 - 4 + 4 * q;          // W % 4 == 0: a chunk is inside or outside as a whole
+            const bool ok = c < nchunk && (unsigned)h < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+            const unsigned vo = ok ? (unsigned)(img + (ci * p.H + h) * p.W + col) * 4u : kOob;
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo, 0, 0));
+        }
+    };
+    fetch(seg0);
   for (int sg = 0; sg < kStemSeg; ++sg) {
     const long long seg = seg0 + sg;
     if (seg >= nseg) break;                                     // wave-uniform
     const int rowi = (int)(seg / spr), ox0 = (int)(seg - (long long)rowi * spr) * 128;
     const int n = rowi / p.Ho, oy = rowi - n * p.Ho;
-    const int h0 = 2 * oy - 1;
-    const long long img = (long long)n * p.Cin * p.H * p.W;
-    bool trow[14];
+    // park the window (the wave's own LDS: no barrier, the previous segment's tap reads are complete - their values fed MFMAs)
 #pragma unroll
-    for (int j = 0; j < 14; ++j) trow[j] = tlive[j] && (unsigned)(h0 + tkh[j]) < (unsigned)p.H;
-    auto load = [&](int it, float (&xa)[14]) {                  // A: the 28 taps of pixel ox0 + 32 it + l31
-        const int ox = ox0 + 32 * it + l31, w0 = 2 * ox - 1;
-        const long long base = img + (long long)h0 * p.W + w0;
-#pragma unroll
-        for (int j = 0; j < 14; ++j) {
-            const bool ok = trow[j] && ox < p.Wo && (unsigned)(w0 + tkw[j]) < (unsigned)p.W;
-            const unsigned vo = ok ? (unsigned)((base + toff[j]) * 4) : kOob;
-            xa[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, vo, 0, 0));
-        }
-    };
+    for (int i = 0; i < 10; ++i) {
+        const int c = lane + 64 * i;
+        const int rc = c / (kXRow / 4), q = c - rc * (kXRow / 4);
+        if (c < nchunk) *reinterpret_cast<f32x4*>(xs + rc * kXPitch + 4 * q) = stage[i];
+    }
+    if (sg + 1 < kStemSeg && seg + 1 < nseg) fetch(seg + 1);
     float* orow = p.y + (long long)n * p.y_nstride + (long long)oy * p.Wo;
-    float xa[2][14];
     float rmean[2] = {0.f, 0.f}, rm2[2] = {0.f, 0.f};
-    load(0, xa[0]);
     static_for<0, 4>([&](auto it_) {
-        constexpr int it = decltype(it_)::value, cur = it & 1;
-        if constexpr (it < 3) load(it + 1, xa[cur ^ 1]);        // next sub-step's taps in flight under this one's MFMAs
+        constexpr int it = decltype(it_)::value;
+        float xa[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) xa[j] = xs[xoff[j] + 64 * it];
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -106,10 +125,10 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const StemParams p) {
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][j], wb[0][j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[cur][j], wb[1][j], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], wb[0][j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], wb[1][j], acc[1], 0, 0, 0);
         }
-        const int oxs = ox0 + 32 * it;                           // (Wo % 8 == 0: a quad is inside or outside as a whole)
+        const int oxs = ox0 + 32 * it;                           // (Wo % 32 == 0: a quad is inside or outside as a whole)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int co = 32 * i + l31;
@@ -261,7 +280,7 @@ bool dcfp_stem_shape(const DcfpConvDesc* d) {
     if (d->Cin * 9 > 28 || d->Cout != 64) return false;
     if (d->x_pitch && d->x_pitch != d->W) return false;
     if (d->dy_pitch && d->dy_pitch != d->Wout) return false;
-    if (d->Wout % 32 != 0) return false;
+    if (d->Wout % 32 != 0 || d->W % 4 != 0) return false;
     return (long long)d->N * d->Cin * d->H * d->W * 4 < 0x7fffff00LL;
 }
 
