@@ -388,6 +388,7 @@ def main():
         # the message names the exchange and the rank (no-op unless --syncbn-p2p; one 4-byte read beside the sync above)
         syncbn_p2p.check_all()
         if val != val:
+            ops.check_fused_status()          # a fused BatchNorm backward that gave up poisons gradients with NaN: say so
             raise RuntimeError("loss is NaN")
         loss["loss"].backward()
         train_pruning.step(seg_model)
@@ -521,6 +522,7 @@ def main():
                "roofline": roof, "cpu_baseline": cpu, "direct_conv": direct, "alt_math": alt, "detail": extra}
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+    ops.check_fused_status()           # a fused BatchNorm backward that gave up is an error, not a number
     if dist.is_initialized():
         from dcfp_amd import syncbn_p2p
         syncbn_p2p.finish()            # an exchange that gave up on a peer is an error, not a number

@@ -97,6 +97,9 @@ SIGNATURES = {
     "dcfp_bn_stats_from_partials_f32": (_I, [_P, _L, _I, _I, _P, _P, _R, _P]),
     "dcfp_bn_bwd_apply_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _P, _P, _F, _P, _I, _P, _P,
                                    _I, _I, _I, _I, _I, _P]),
+    "dcfp_bn_bwd_fused_sync_bytes": (_Z, [_I, _I, _I]),
+    "dcfp_bn_bwd_fused_f32": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _I, _I, _I, _I, _I,
+                                   _P, _P, _P, _P, _P, _Z, C.c_uint32, C.c_uint32, _P, _P]),
     "dcfp_maxpool3x3s2_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dcfp_maxpool3x3s2_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dcfp_rowsum_f32": (_I, [_P, _L, _P, _F, _I, _I, _I, _P]),

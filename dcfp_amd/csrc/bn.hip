@@ -22,12 +22,16 @@ struct BnPlan {
     int chunk_elems;  // elements (of the N*HW per-channel population) per block, multiple of 4
 };
 
+// One plan for every per-channel reduction (statistics, backward sums, the fused backward): a block owns at most
+// kChunkElems = 8192 elements of a channel's N*HW population - 8 float4 per thread and tensor, which is what the fused
+// backward can keep in registers between its two phases (round 4; rounds 1-3 capped the grid at ~4096 blocks instead,
+// up to 32768 elements per block).  Fused and two-kernel backward share the plan, so their sums are the same bits.
+constexpr int kChunkElems = 8192;
+
 BnPlan bn_plan(int N, int C, int HW) {
+    (void)C;
     const long long E = (long long)N * HW;
-    long long by_size = (E + 2047) / 2048;
-    long long by_grid = 4096 / (C > 0 ? C : 1);
-    if (by_grid < 1) by_grid = 1;
-    long long chunks = by_size < by_grid ? by_size : by_grid;
+    long long chunks = (E + kChunkElems - 1) / kChunkElems;
     if (chunks < 1) chunks = 1;
     long long ce = (E + chunks - 1) / chunks;
     ce = (ce + 1023) / 1024 * 1024;   // whole wave iterations (256 elements per wave): the bit-mask ReLU path needs them
@@ -37,6 +41,19 @@ BnPlan bn_plan(int N, int C, int HW) {
     p.chunks = (int)chunks;
     p.chunk_elems = (int)ce;
     return p;
+}
+
+// The two backward sums of one float4 and the value of dx, written ONE way (no contraction: the two-kernel path and the
+// fused kernel must round identically - the data-parallel path runs the former, the plain step the latter, and the
+// tests hold them bit-identical).
+__device__ __forceinline__ void bwd_accumulate(const float4& g, const float4& xv, float mu, float& s1, float& s2) {
+#pragma clang fp contract(off)
+    s1 += (g.x + g.y) + (g.z + g.w);
+    s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+}
+__device__ __forceinline__ float bwd_dx(float g, float xv, float mu, float mean_dy, float k, float gi) {
+#pragma clang fp contract(off)
+    return (g - mean_dy - (xv - mu) * k) * gi;
 }
 
 // ---- stats: shifted sums  S1 = sum(x-K), S2 = sum((x-K)^2), K = x[0,c,0]
@@ -210,8 +227,7 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
                 g.x = mask_bit(mw, iw, 0) ? g.x : 0.f; g.y = mask_bit(mw, iw, 1) ? g.y : 0.f;
                 g.z = mask_bit(mw, iw, 2) ? g.z : 0.f; g.w = mask_bit(mw, iw, 3) ? g.w : 0.f;
             }
-            s1 += (g.x + g.y) + (g.z + g.w);
-            s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+            bwd_accumulate(g, xv, mu, s1, s2);
         }
     } else {
         for (long long e = e0 + threadIdx.x; e < e1; e += kThreads) {
@@ -233,22 +249,34 @@ bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, long long dy_nstride,
     }
 }
 
-// o3 (nullable): dgamma = sum(dy*(x-mean)) * rsqrt(var + eps), saving the caller three launches
-__global__ void bn_pair_final_kernel(int C, int chunks, const float* __restrict__ part,
+// The per-channel totals of `chunks` (s1, s2) partial pairs, by ONE wave, in an order both backward paths share:
+// value q = 2 * chunk + which (which = 0: s1, 1: s2) goes to lane q % 64, which adds its values in ascending q in fp64;
+// the 32 lanes of a parity class are then combined by an xor butterfly (offsets 2 .. 32: every lane of the class ends
+// with the same bits).  Returns the class total: s1's in even lanes, s2's in odd lanes.  value_of(j) = value q = lane + 64 j.
+template <class F>
+__device__ __forceinline__ double wave_pair_totals(int n2, int lane, F value_of) {
+    double acc = 0.0;
+    for (int j = 0; lane + 64 * j < n2; ++j) acc += (double)value_of(j);
+#pragma unroll
+    for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    return acc;
+}
+
+// o3 (nullable): dgamma = sum(dy*(x-mean)) * rsqrt(var + eps), saving the caller three launches.  One wave per channel.
+__global__ void __launch_bounds__(64) bn_pair_final_kernel(int C, int chunks, const float* __restrict__ part,
                                      float* __restrict__ o1, float* __restrict__ o2,
                                      const float* __restrict__ var, float eps, float* __restrict__ o3,
                                      float* __restrict__ o4) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double S1 = 0.0, S2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        S1 += (double)part[((long long)c * chunks + k) * 2 + 0];
-        S2 += (double)part[((long long)c * chunks + k) * 2 + 1];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float* pc = part + (long long)c * chunks * 2;
+    const double t = wave_pair_totals(2 * chunks, lane, [&](int j) { return pc[lane + 64 * j]; });
+    const double S1 = __shfl(t, 0, 64), S2 = __shfl(t, 1, 64);
+    if (lane == 0) {
+        o1[c] = (float)S1;
+        o2[c] = (float)S2;
+        if (o3) o3[c] = (float)S2 * rsqrtf(var[c] + eps);
+        if (o4) o4[c] = (float)S1;
     }
-    o1[c] = (float)S1;
-    o2[c] = (float)S2;
-    if (o3) o3[c] = (float)S2 * rsqrtf(var[c] + eps);
-    if (o4) o4[c] = (float)S1;
 }
 
 // SyncBatchNorm forward combine: allv[r] = (mean_r[C], var_r[C], count_r) gathered from every rank ->
@@ -462,10 +490,10 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
                 g.z = mask_bit(mw, iw, 2) ? g.z : 0.f; g.w = mask_bit(mw, iw, 3) ? g.w : 0.f;
             }
             float4 o;
-            o.x = (g.x - mean_dy - (xv.x - mu) * k) * gi;
-            o.y = (g.y - mean_dy - (xv.y - mu) * k) * gi;
-            o.z = (g.z - mean_dy - (xv.z - mu) * k) * gi;
-            o.w = (g.w - mean_dy - (xv.w - mu) * k) * gi;
+            o.x = bwd_dx(g.x, xv.x, mu, mean_dy, k, gi);
+            o.y = bwd_dx(g.y, xv.y, mu, mean_dy, k, gi);
+            o.z = bwd_dx(g.z, xv.z, mu, mean_dy, k, gi);
+            o.w = bwd_dx(g.w, xv.w, mu, mean_dy, k, gi);
             if (dx_pitch) { const int h = i / W; *reinterpret_cast<float4*>(dxr + h * dx_pitch + (i - h * W)) = o; }
             else *reinterpret_cast<float4*>(dxr + i) = o;
             if (drr) *reinterpret_cast<float4*>(drr + i) = g;
@@ -479,6 +507,167 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
             if (dx_pitch) { const int h = i / W; dxr[h * dx_pitch + (i - h * W)] = o; }
             else dxr[i] = o;
             if (drr) drr[i] = g;
+        }
+    }
+}
+
+// ---- backward, both stages in ONE launch (round 4).  The two-kernel backward reads dy and x twice (20 B/element:
+// 8 for the sums, 12 for dx); here block (c, chunk) loads its <= 8192 elements of dy and x ONCE into registers (8 float4
+// per thread and tensor), publishes its two partial sums, waits for the other blocks of its channel, and computes dx
+// from the registers: 12 B/element.  Hand-off between the blocks of a channel (they may sit on different XCDs, whose
+// L2s are not coherent): every partial is ONE 8-byte granule {tag = epoch, value}, stored and polled with relaxed
+// agent-scope atomics (write-through / L2-bypassing) - the data is the flag, no fence, no counter
+// (cdna_hip_programming.md section 6, Guideline 16, form R2).  `sync` holds 2 granules per (channel, chunk); the caller
+// zero-fills it once and passes a strictly increasing epoch (never 0) with every call, so a granule of an earlier
+// call can never pass for this one's.  Forward progress: blocks are dispatched in blockIdx order and a block only
+// waits for the `chunks` blocks of its own channel (consecutive ids, <= kFusedMaxChunks of them, far below what the
+// chip holds), so the oldest unfinished channel always has all its blocks resident; the spin is bounded all the same
+// (spin_limit polls of ~0.3 us: give up -> dx of this block = NaN, *status = epoch).
+// Arithmetic and summation order are those of bn_bwd_reduce_partial_kernel + bn_pair_final_kernel + bn_bwd_apply_kernel
+// (same plan, same helpers): the results are the same bits as the two-kernel path's.
+typedef __attribute__((address_space(1))) unsigned long long bn_gu64;
+constexpr int kFusedPollMax = 8;                            // granules per polling lane
+constexpr int kFusedMaxChunks = 32 * kFusedPollMax;         // 256 blocks per channel = 2M elements (the stem at 4 x 512 x 1024)
+constexpr int kFusedIters = kChunkElems / (4 * kThreads);   // 8 float4 per thread and tensor
+
+struct BnFusedParams {
+    const float* dy; long long dy_nstride;
+    const float* x; const float* y; long long y_nstride;
+    const float* mean; const float* var; const float* gamma; const float* beta;
+    float eps, inv_count;
+    float* dx; float* dres;
+    int C, HW, E, chunk_elems, chunks, W, dx_pitch;
+    unsigned long long* sync; unsigned epoch, spin_limit; int* status;
+    float* sum_dy; float* sum_dy_xmu; float* dgamma; float* dbeta;
+};
+
+template <int RELU, bool DRES>
+__global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedParams p) {
+    __shared__ float red[4];
+    __shared__ double tot[2];
+    __shared__ int failed;
+    const int c = blockIdx.x / p.chunks, chunk = blockIdx.x - c * p.chunks;
+    const int HW = p.HW, C = p.C;
+    const float mu = p.mean[c];
+    const float istd = 1.0f / sqrtf(p.var[c] + p.eps);
+    const float gm = p.gamma[c];
+    const float bt = RELU == 2 ? p.beta[c] : 0.f;
+    const int e0 = chunk * p.chunk_elems;
+    const int e1 = e0 + p.chunk_elems < p.E ? e0 + p.chunk_elems : p.E;
+    const long long coff = (long long)c * HW;
+    const long long x_nstride = (long long)C * HW;
+    if (threadIdx.x == 0) failed = 0;
+
+    // ---- phase 1: the block's elements into registers, g = dy * mask in place of dy
+    float4 g[kFusedIters], xv[kFusedIters];
+    int nn[kFusedIters], ii[kFusedIters];
+#pragma unroll
+    for (int k = 0; k < kFusedIters; ++k) {
+        const int e = e0 + 4 * (int)threadIdx.x + 4 * kThreads * k;
+        const int n = (int)((unsigned)e / (unsigned)HW);
+        nn[k] = n;
+        ii[k] = e - n * HW;
+        if (e < e1) {
+            g[k] = *reinterpret_cast<const float4*>(p.dy + (long long)n * p.dy_nstride + coff + ii[k]);
+            xv[k] = *reinterpret_cast<const float4*>(p.x + (long long)n * x_nstride + coff + ii[k]);
+        } else {
+            g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kFusedIters; ++k) {
+        const int e = e0 + 4 * (int)threadIdx.x + 4 * kThreads * k;
+        if (e < e1) {
+            if (RELU == 1) {
+                const float4 yv = *reinterpret_cast<const float4*>(p.y + (long long)nn[k] * p.y_nstride + coff + ii[k]);
+                g[k].x = yv.x > 0.f ? g[k].x : 0.f; g[k].y = yv.y > 0.f ? g[k].y : 0.f;
+                g[k].z = yv.z > 0.f ? g[k].z : 0.f; g[k].w = yv.w > 0.f ? g[k].w : 0.f;
+            } else if (RELU == 2) {
+                g[k].x = bn_val(xv[k].x, mu, istd, gm, bt) > 0.f ? g[k].x : 0.f;
+                g[k].y = bn_val(xv[k].y, mu, istd, gm, bt) > 0.f ? g[k].y : 0.f;
+                g[k].z = bn_val(xv[k].z, mu, istd, gm, bt) > 0.f ? g[k].z : 0.f;
+                g[k].w = bn_val(xv[k].w, mu, istd, gm, bt) > 0.f ? g[k].w : 0.f;
+            } else if (RELU == 3) {
+                const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(p.y) +
+                                               ((long long)nn[k] * C + c) * (long long)(HW >> 6);
+                const int iw = ii[k] - 4 * (int)(threadIdx.x & 63);
+                g[k].x = mask_bit(mw, iw, 0) ? g[k].x : 0.f; g[k].y = mask_bit(mw, iw, 1) ? g[k].y : 0.f;
+                g[k].z = mask_bit(mw, iw, 2) ? g[k].z : 0.f; g[k].w = mask_bit(mw, iw, 3) ? g[k].w : 0.f;
+            }
+            bwd_accumulate(g[k], xv[k], mu, s1, s2);
+        }
+    }
+    const float t1 = block_sum_256(s1, red);
+    const float t2 = block_sum_256(s2, red);
+
+    // ---- hand-off: publish the block's granules, collect the channel's
+    bn_gu64* gr = (bn_gu64*)(p.sync + (long long)c * p.chunks * 2);
+    const unsigned long long tag = (unsigned long long)p.epoch << 32;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(gr + chunk * 2 + 0, tag | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gr + chunk * 2 + 1, tag | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {          // ONE wave polls; lane l takes granules l, l + 64, ... - all loads of a round in flight together
+        const int lane = (int)threadIdx.x, n2 = 2 * p.chunks;
+        unsigned long long v[kFusedPollMax];
+#pragma unroll
+        for (int j = 0; j < kFusedPollMax; ++j)
+            v[j] = lane + 64 * j < n2 ? __hip_atomic_load(gr + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < kFusedPollMax; ++j) ok &= (v[j] >> 32) == p.epoch;
+            if (__all(ok)) break;
+            if (++spins > p.spin_limit) { failed = 1; break; }          // (wave-uniform: every lane counts the same rounds)
+            __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+            for (int j = 0; j < kFusedPollMax; ++j)
+                if ((v[j] >> 32) != p.epoch)
+                    v[j] = __hip_atomic_load(gr + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the channel's sums: bn_pair_final_kernel's order
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < kFusedPollMax; ++j)
+            if (lane + 64 * j < n2) acc += (double)__uint_as_float((unsigned)v[j]);
+#pragma unroll
+        for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane < 2) tot[lane] = acc;
+        if (lane == 0 && failed && p.status) atomicExch(p.status, (int)p.epoch);
+    }
+    __syncthreads();
+    const bool bad = failed != 0;
+    const float S1f = (float)tot[0], S2f = (float)tot[1];
+    if (chunk == 0 && threadIdx.x == 0) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+        p.sum_dy[c] = bad ? nanv : S1f;
+        p.sum_dy_xmu[c] = bad ? nanv : S2f;
+        if (p.dgamma) p.dgamma[c] = bad ? nanv : S2f * rsqrtf(p.var[c] + p.eps);
+        if (p.dbeta) p.dbeta[c] = bad ? nanv : S1f;
+    }
+
+    // ---- phase 2: dx from the registers (bn_bwd_apply_kernel's expressions)
+    const float mean_dy = S1f * p.inv_count;
+    const float kk = S2f * p.inv_count * istd * istd;
+    const float gi = bad ? __uint_as_float(0x7fc00000u) : gm * istd;
+    const long long plane = p.dx_pitch ? (long long)(HW / p.W) * p.dx_pitch : HW;
+#pragma unroll
+    for (int k = 0; k < kFusedIters; ++k) {
+        const int e = e0 + 4 * (int)threadIdx.x + 4 * kThreads * k;
+        if (e < e1) {
+            const long long row = (long long)nn[k] * C + c;
+            float4 o;
+            o.x = bwd_dx(g[k].x, xv[k].x, mu, mean_dy, kk, gi);
+            o.y = bwd_dx(g[k].y, xv[k].y, mu, mean_dy, kk, gi);
+            o.z = bwd_dx(g[k].z, xv[k].z, mu, mean_dy, kk, gi);
+            o.w = bwd_dx(g[k].w, xv[k].w, mu, mean_dy, kk, gi);
+            float* dxr = p.dx + row * plane;
+            if (p.dx_pitch) { const int h = ii[k] / p.W; *reinterpret_cast<float4*>(dxr + h * p.dx_pitch + (ii[k] - h * p.W)) = o; }
+            else *reinterpret_cast<float4*>(dxr + ii[k]) = o;
+            if (DRES) *reinterpret_cast<float4*>(p.dres + row * HW + ii[k]) = g[k];
         }
     }
 }
@@ -600,7 +789,7 @@ extern "C" int dcfp_bn_bwd_reduce_f32(const float* dy, int64_t dy_nstride, const
     if (vec) { if (relu == 3) LAUNCH_RED(true, 3); else if (relu == 2) LAUNCH_RED(true, 2); else if (relu == 1) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
     else     { if (relu == 2) LAUNCH_RED(false, 2); else if (relu == 1) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
-    hipLaunchKernelGGL(bn_pair_final_kernel, dim3((C + 255) / 256), dim3(256), 0, dcfp_s(stream), C,
+    hipLaunchKernelGGL(bn_pair_final_kernel, dim3((unsigned)C), dim3(64), 0, dcfp_s(stream), C,
                        p.chunks, part, sum_dy, sum_dy_xmu, var, eps, dgamma, dbeta);
     DCFP_RETURN_LAUNCH();
 }
@@ -648,6 +837,60 @@ extern "C" int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const 
     if (vec) { if (relu == 3) LAUNCH_APP(true, 3); else if (relu == 2) LAUNCH_APP(true, 2); else if (relu == 1) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
     else     { if (relu == 2) LAUNCH_APP(false, 2); else if (relu == 1) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
 #undef LAUNCH_APP
+    DCFP_RETURN_LAUNCH();
+}
+
+// Bytes of the hand-off buffer of dcfp_bn_bwd_fused_f32 for this shape (0: the shape is not supported by the fused kernel)
+extern "C" size_t dcfp_bn_bwd_fused_sync_bytes(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0 || HW % 4 != 0) return 0;
+    const long long E = (long long)N * HW;
+    if (E >= 0x7fffffffLL - kChunkElems) return 0;
+    const BnPlan p = bn_plan(N, C, HW);
+    if (p.chunks > kFusedMaxChunks || p.chunk_elems > kChunkElems) return 0;
+    if ((long long)C * p.chunks > 0x7fffffffLL) return 0;
+    return (size_t)C * p.chunks * 2 * sizeof(unsigned long long);
+}
+
+extern "C" int dcfp_bn_bwd_fused_f32(const float* dy, int64_t dy_nstride, const float* x, const float* y,
+                                     int64_t y_nstride, const float* mean, const float* var, const float* gamma,
+                                     const float* beta, float eps, float count, int relu, float* dx, float* d_residual,
+                                     int N, int C, int HW, int W, int dx_pitch, float* sum_dy, float* sum_dy_xmu,
+                                     float* dgamma, float* dbeta, void* sync, size_t sync_bytes, uint32_t epoch,
+                                     uint32_t spin_limit, int32_t* status, dcfp_stream_t stream) {
+    if (!dy || !x || !mean || !var || !gamma || !dx || !sum_dy || !sum_dy_xmu || !sync || N <= 0 || C <= 0 || HW <= 0 ||
+        !(count > 0.f) || epoch == 0)
+        return DCFP_E_BADDESC;
+    if (relu < 0 || relu > 3 || ((relu == 1 || relu == 3) && !y) || (relu == 2 && !beta)) return DCFP_E_BADDESC;
+    if (dx_pitch && (W <= 0 || HW % W != 0 || dx_pitch < W)) return DCFP_E_BADDESC;
+    if (dx_pitch == W) dx_pitch = 0;
+    if (dy_nstride == 0) dy_nstride = (int64_t)C * HW;
+    if (y_nstride == 0) y_nstride = (int64_t)C * HW;
+    const size_t need = dcfp_bn_bwd_fused_sync_bytes(N, C, HW);
+    if (need == 0) return DCFP_E_UNSUPPORTED;
+    if (sync_bytes < need || (reinterpret_cast<uintptr_t>(sync) & 7u)) return DCFP_E_WORKSPACE;
+    const bool vec = (dy_nstride % 4 == 0) && (y_nstride % 4 == 0) && dcfp_aligned16(dy) && dcfp_aligned16(x) &&
+                     dcfp_aligned16(dx) && (relu != 1 || dcfp_aligned16(y)) &&
+                     (!d_residual || dcfp_aligned16(d_residual)) && (!dx_pitch || (W % 4 == 0 && dx_pitch % 4 == 0));
+    if (!vec) return DCFP_E_UNSUPPORTED;
+    if (relu == 3 && !(HW % 256 == 0 && dy_nstride == (int64_t)C * HW)) return DCFP_E_UNSUPPORTED;
+    const BnPlan pl = bn_plan(N, C, HW);
+    BnFusedParams p;
+    p.dy = dy; p.dy_nstride = dy_nstride; p.x = x; p.y = y; p.y_nstride = y_nstride;
+    p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.eps = eps; p.inv_count = 1.0f / count;
+    p.dx = dx; p.dres = d_residual; p.C = C; p.HW = HW; p.E = (int)((long long)N * HW);
+    p.chunk_elems = pl.chunk_elems; p.chunks = pl.chunks; p.W = W; p.dx_pitch = dx_pitch;
+    p.sync = static_cast<unsigned long long*>(sync); p.epoch = epoch;
+    p.spin_limit = spin_limit ? spin_limit : (1u << 18); p.status = status;
+    p.sum_dy = sum_dy; p.sum_dy_xmu = sum_dy_xmu; p.dgamma = dgamma; p.dbeta = dbeta;
+    const dim3 grid((unsigned)((long long)C * pl.chunks));
+    const size_t lds = 0;
+#define LAUNCH_FUSED(R)                                                                                        \
+    do {                                                                                                       \
+        if (d_residual) hipLaunchKernelGGL((bn_bwd_fused_kernel<R, true>), grid, dim3(kThreads), lds, dcfp_s(stream), p);  \
+        else hipLaunchKernelGGL((bn_bwd_fused_kernel<R, false>), grid, dim3(kThreads), lds, dcfp_s(stream), p);            \
+    } while (0)
+    if (relu == 3) LAUNCH_FUSED(3); else if (relu == 2) LAUNCH_FUSED(2); else if (relu == 1) LAUNCH_FUSED(1); else LAUNCH_FUSED(0);
+#undef LAUNCH_FUSED
     DCFP_RETURN_LAUNCH();
 }
 

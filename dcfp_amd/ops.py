@@ -324,6 +324,10 @@ def _rp(run):
 
 FANIN_RED_USED = [0]     # BatchNorm backwards that took their sums from a fan-in epilogue (tests / bench)
 FANIN_BN_SUMS = os.environ.get("DCFP_FANIN_BN_SUMS", "1") not in ("0",)   # =0: every BatchNorm backward runs its own reduce kernel (A/B)
+# =2: the fan-in epilogue reduces bn3's gradient even where the fused BatchNorm backward applies (round-3 behaviour).  By
+# default (1) it does so only under SyncBN: the fused backward reads dy and x once anyway (12 B/element, what the
+# apply-only pass behind the epilogue sums costs), so the epilogue's extra reads would buy nothing there
+FANIN_BN_SUMS_ALWAYS = os.environ.get("DCFP_FANIN_BN_SUMS", "1") == "2"
 KEEP_XFORM = os.environ.get("DCFP_KEEP_XFORM", "1") not in ("0",)   # =0: weight gradients transform x again (A/B)
 
 
@@ -666,6 +670,76 @@ def bn_bwd_apply(dy, x, y, mean, var, gamma, beta, eps, s1, s2, count, relu, wan
     return dx, dres
 
 
+# ---- the fused BatchNorm backward (dcfp_bn_bwd_fused_f32): both stages in one launch, dy and x read once.
+# DCFP_BN_FUSED=0 keeps the two-kernel path (which the data-parallel path always takes: its sums cross the ranks).
+BN_BWD_FUSED = os.environ.get("DCFP_BN_FUSED", "1") != "0"
+FUSED_BN_USED = [0]            # launches since import (tests read it)
+_FUSED_SYNC = {}               # (device index, stream) -> [hand-off buffer, last epoch, status word]
+
+
+def _fused_sync(nbytes, device):
+    """The hand-off buffer of the fused kernel's blocks, its next epoch and the give-up status word: zero-filled when
+    created or grown, epochs strictly increasing per buffer (the contract of dcfp_bn_bwd_fused_f32)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    st = _FUSED_SYNC.get(key)
+    if st is None:
+        st = [None, 0, torch.zeros(1, dtype=torch.int32, device=device)]
+        _FUSED_SYNC[key] = st
+    if st[0] is None or st[0].numel() < nbytes or st[1] >= 0xfffffff0:
+        st[0] = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        st[1] = 0
+    st[1] += 1
+    return st[0], st[1], st[2]
+
+
+def check_fused_status():
+    """Once per step, next to the step's own host synchronisation: raise if a block of a fused BatchNorm backward gave
+    up waiting for the other blocks of its channel (its outputs were poisoned with NaN)."""
+    for (dev, _), st in _FUSED_SYNC.items():
+        v = int(st[2].item())
+        if v != 0:
+            raise RuntimeError("dcfp_amd: fused BatchNorm backward (call %d on device %s) gave up waiting for the blocks of "
+                               "a channel; its outputs are NaN.  DCFP_BN_FUSED=0 selects the two-kernel path" % (v, dev))
+
+
+def bn_bwd_fused(dy, x, y, mean, var, gamma, beta, eps, count, relu, want_residual, dx_out=None, dgamma=None, dbeta=None):
+    """bn_bwd_reduce + bn_bwd_apply in one launch (same bits).  Returns (s1, s2, dgamma, dx, dres), or None when the
+    shape is not supported by the fused kernel (the caller then takes the two-kernel path)."""
+    N, Cc, H, W = x.shape
+    L = _lib.lib()
+    need = L.dcfp_bn_bwd_fused_sync_bytes(N, Cc, H * W)
+    if need == 0:
+        return None
+    dy, dns = _batch_strided(dy)
+    dxp = 0
+    if dx_out is not None:
+        dxp = _pitch_of(dx_out)
+        if tuple(dx_out.shape) != tuple(x.shape) or not dxp:
+            raise RuntimeError("bn_bwd_fused: dx_out must be a row-pitched buffer of x's shape")
+        dx = dx_out
+    else:
+        dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_residual else None
+    s = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    sync, epoch, status = _fused_sync(need, x.device)
+    nbytes = (12.0 + (4.0 if relu == 1 else 0.125 if relu == 3 else 0.0) + (4.0 if want_residual else 0.0)) * x.numel()
+    rc = [0]
+
+    def run():
+        rc[0] = L.dcfp_bn_bwd_fused_f32(_p(dy), dns, _p(x), _p(y) if relu in (1, 3) else None, 0, _p(mean), _p(var),
+                                        _p(gamma), _p(beta), float(eps), float(count), int(relu), _p(dx), _p(dres),
+                                        N, Cc, H * W, W, dxp, _p(s[0]), _p(s[1]), _p(dgamma), _p(dbeta), _p(sync),
+                                        sync.numel(), epoch, 0, _p(status), _stream())
+    _timed("bn_bwd_fused", None, nbytes, run)
+    if rc[0] == _lib.E_UNSUPPORTED:
+        return None
+    check(rc[0], "bn_bwd_fused")
+    FUSED_BN_USED[0] += 1
+    return s[0], s[1], dgamma, dx, dres
+
+
 def _sync_group(group):
     if group is False or not dist.is_available() or not dist.is_initialized():
         return None
@@ -865,6 +939,24 @@ def bn_backward_impl(dy, x, y, gamma, beta, state, relu, training, eps, want_res
     otherwise the mask is re-derived from x inside the kernels (pass y=None).  between: optional callable
     run after the reduction (and the start of the SyncBN exchange) and before dx - independent work
     that hides the exchange."""
+    if BN_BWD_FUSED and training and pre is None and state[3] is None and not isinstance(state[2], torch.Tensor):
+        # no exchange between the two stages: one launch, dy and x read once
+        mask = state[4] if len(state) > 4 else None
+        if relu and mask is not None:
+            frelu, fy = 3, mask
+        else:
+            frelu, fy = ((1 if y is not None else 2) if relu else 0), y
+        gp = gparam if gparam is not None else gamma
+        bp = bparam if bparam is not None else beta
+        tg, kg = arena.grad_target(gp)
+        tb, kb = arena.grad_target(bp)
+        out = bn_bwd_fused(dy, x, fy, state[0], state[1], gamma, beta, eps, state[2], frelu, want_res, dx_out,
+                           dgamma=tg, dbeta=tb)
+        if out is not None:
+            dgamma = arena.grad_commit(gp, tg, kg, add_into)
+            dbeta = arena.grad_commit(bp, tb, kb, add_into)
+            mid = between() if between is not None else None
+            return (out[3], dgamma, dbeta, out[4]) + ((mid,) if between is not None else ())
     red = bn_backward_reduce(dy, x, y, gamma, beta, state, relu, training, gparam, bparam, eps, pre=pre)
     mid = between() if between is not None else None
     out = bn_backward_apply(dy, x, gamma, beta, state, red, eps, want_res, dx_out)
@@ -1000,7 +1092,8 @@ class BottleneckFn(torch.autograd.Function):
         ctx.rec = None
         # (only when a backward pass can follow: a training-mode forward under no_grad builds no graph, and the record on
         #  its output would keep bn3's input alive for nothing)
-        if FANIN_BN_SUMS and len(st3) > 4 and any(ctx.needs_input_grad):
+        fused_bn3 = BN_BWD_FUSED and st3[3] is None and not FANIN_BN_SUMS_ALWAYS     # bn3's backward will be ONE launch
+        if FANIN_BN_SUMS and not fused_bn3 and len(st3) > 4 and any(ctx.needs_input_grad):
             ctx.rec = {"c3": c3, "mask": st3[4], "mean": st3[0]}
             out._dcfp_bn3_rec = ctx.rec
         return out

@@ -317,6 +317,25 @@ int dcfp_bn_bwd_apply_f32(const float* dy, int64_t dy_nstride, const float* x,
                           int N, int C, int HW, int W, int dx_pitch /* as y_pitch above, for dx */,
                           dcfp_stream_t stream);
 
+/* Backward stages 1 + 2 in ONE launch, for a BatchNorm whose sums need no exchange between ranks (plain
+ * nn.BatchNorm2d, or SyncBatchNorm at world size 1): a block keeps its <= 8192 elements of dy and x in registers
+ * between the two stages, so both tensors are read once (12 B/element instead of 20).  Outputs are the same bits as
+ * dcfp_bn_bwd_reduce_f32 followed by dcfp_bn_bwd_apply_f32 (same plan, same summation order).  Arguments as there;
+ * `count` = N*HW.  The blocks of a channel meet through `sync` (dcfp_bn_bwd_fused_sync_bytes(N,C,HW) bytes, 8-byte
+ * aligned; 0 = shape not supported, the call then returns DCFP_E_UNSUPPORTED and the two-kernel path applies):
+ *   - the CALLER zero-fills `sync` once (it may serve every later call on the same stream, any shape that fits) and
+ *     passes a strictly increasing `epoch` >= 1 with every call on it (re-zero before wrapping to 1);
+ *   - spin_limit: polls (~0.3 us each) after which a block gives up waiting for its channel's other blocks
+ *     (0 = default 2^18, ~0.1 s): its dx and the channel's sums become NaN and *status (nullable device int32, zeroed once by
+ *     the caller, never written otherwise) = epoch.  Needs 16-byte aligned tensors, HW % 4 == 0. */
+size_t dcfp_bn_bwd_fused_sync_bytes(int N, int C, int HW);
+int dcfp_bn_bwd_fused_f32(const float* dy, int64_t dy_nstride, const float* x, const float* y,
+                          int64_t y_nstride, const float* mean, const float* var, const float* gamma,
+                          const float* beta, float eps, float count, int relu, float* dx, float* d_residual,
+                          int N, int C, int HW, int W, int dx_pitch, float* sum_dy, float* sum_dy_xmu,
+                          float* dgamma, float* dbeta, void* sync, size_t sync_bytes, uint32_t epoch,
+                          uint32_t spin_limit, int32_t* status, dcfp_stream_t stream);
+
 /* ------------------------------------------------- element-wise / pooling
  * MaxPool2d(3,2,1) (resnet.py:100,149): -inf padding, first-max index. */
 int dcfp_maxpool3x3s2_fwd_f32(const float* x, float* y, int32_t* argmax,

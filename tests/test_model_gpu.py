@@ -489,12 +489,15 @@ if __name__ == "__main__" and "--fanin-child" in __import__("sys").argv:
     _fanin_child()
 
 
-def test_fanin_epilogue_bn_sums(cuda):
+def test_fanin_epilogue_bn_sums(cuda, monkeypatch):
     """The fan-in dgrad that also reduces its result for the previous block's bn3 (ops.conv2d_dgrad_fanin_red):
     dx the same bits as the plain fan-in, the finished sums against an fp64 evaluation from the mask bits and against
     the bn_bwd_reduce kernel they replace; then a DeepLabv3-R50 step at 2x3x512x1024 with and without the coupling:
     the coupled path must actually be taken and move no parameter gradient by more than fp32 summation noise."""
     from dcfp_amd import ops
+    # (without SyncBN the fused BatchNorm backward makes the epilogue sums unnecessary and they are off by default:
+    #  DCFP_FANIN_BN_SUMS=2 - this switch - keeps them, which is what the data-parallel path runs)
+    monkeypatch.setattr(ops, "FANIN_BN_SUMS_ALWAYS", True)
     dev = cuda
     g = torch.Generator().manual_seed(3)
     N, Cin, Cout, H, W = 2, 1024, 256, 64, 128                     # layer3 conv1 geometry at 2x3x512x1024

@@ -127,6 +127,8 @@ def main(argv=None):
             if not bool(loss["loss"] == loss["loss"]):     # (train.py:260-261 asserts this - a host sync per step, as there)
                 from dcfp_amd import syncbn_p2p
                 syncbn_p2p.check_all()                     # a SyncBN exchange that gave up on a peer poisons with NaN: say so
+                from dcfp_amd import ops as _ops
+                _ops.check_fused_status()                  # ... and so does a fused BatchNorm backward that gave up
                 raise AssertionError("loss is NaN")
             reduce_loss = engine.all_reduce_tensor(loss["loss"])
             loss["loss"].backward()
@@ -145,7 +147,8 @@ def main(argv=None):
                     torch.save(seg_model.state_dict(), osp.join(args.snapshot_dir, "CS_scenes_%d.pth" % done))
         if main_flag and train_pruning is not None:
             train_pruning.export_eic(osp.join(args.snapshot_dir, "score.pth"))
-        from dcfp_amd import syncbn_p2p
+        from dcfp_amd import syncbn_p2p, ops as _ops
+        _ops.check_fused_status()
         syncbn_p2p.finish()            # DCFP_SYNCBN_P2P=1: no exchange may have given up on a peer
 
 
