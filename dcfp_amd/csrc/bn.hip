@@ -6,6 +6,7 @@
 // segment or one (c, chunk) slice per 256-thread block, wave-shuffle reductions,
 // per-block partials combined in a fixed order in fp64 (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,17 +44,20 @@ BnPlan bn_plan(int N, int C, int HW) {
     return p;
 }
 
-// The two backward sums of one float4 and the value of dx, written ONE way (no contraction: the two-kernel path and the
-// fused kernel must round identically - the data-parallel path runs the former, the plain step the latter, and the
-// tests hold them bit-identical).
+// The two backward sums of one float4 and the value of dx, written ONE way: explicit fused multiply-adds under
+// `fp contract(off)` - the rounding is then the same in every kernel that inlines these (the two-kernel path and the fused
+// kernel must agree bit for bit: the data-parallel path runs the former, the plain step the latter, and the tests hold them
+// identical), and no product is rounded on its own where hipcc's default contraction would have fused it.
 __device__ __forceinline__ void bwd_accumulate(const float4& g, const float4& xv, float mu, float& s1, float& s2) {
 #pragma clang fp contract(off)
     s1 += (g.x + g.y) + (g.z + g.w);
-    s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+    const float a = fmaf(g.x, xv.x - mu, g.y * (xv.y - mu));
+    const float b = fmaf(g.z, xv.z - mu, g.w * (xv.w - mu));
+    s2 += a + b;
 }
 __device__ __forceinline__ float bwd_dx(float g, float xv, float mu, float mean_dy, float k, float gi) {
 #pragma clang fp contract(off)
-    return (g - mean_dy - (xv - mu) * k) * gi;
+    return fmaf(-(xv - mu), k, g - mean_dy) * gi;
 }
 
 // ---- stats: shifted sums  S1 = sum(x-K), S2 = sum((x-K)^2), K = x[0,c,0]
@@ -527,6 +531,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
 // (same plan, same helpers): the results are the same bits as the two-kernel path's.
 typedef __attribute__((address_space(1))) unsigned long long bn_gu64;
 constexpr int kFusedPollMax = 8;                            // granules per polling lane
+constexpr int kFusedFlatChunks = 16;                        // up to here every block reads all partials of its channel
 constexpr int kFusedMaxChunks = 32 * kFusedPollMax;         // 256 blocks per channel = 2M elements (the stem at 4 x 512 x 1024)
 constexpr int kFusedIters = kChunkElems / (4 * kThreads);   // 8 float4 per thread and tensor
 
@@ -544,7 +549,7 @@ struct BnFusedParams {
 template <int RELU, bool DRES>
 __global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedParams p) {
     __shared__ float red[4];
-    __shared__ double tot[2];
+    __shared__ float tot[2];
     __shared__ int failed;
     const int c = blockIdx.x / p.chunks, chunk = blockIdx.x - c * p.chunks;
     const int HW = p.HW, C = p.C;
@@ -602,15 +607,21 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedPar
     const float t1 = block_sum_256(s1, red);
     const float t2 = block_sum_256(s2, red);
 
-    // ---- hand-off: publish the block's granules, collect the channel's
-    bn_gu64* gr = (bn_gu64*)(p.sync + (long long)c * p.chunks * 2);
+    // ---- hand-off: publish the block's granules, collect the channel's.  Channels of more than kFusedFlatChunks blocks
+    // meet in two levels: only the block of the LAST chunk (dispatched last, so it rarely waits) reads all the partials; it
+    // publishes the two totals as granules of their own and the others poll just those - every block reading every
+    // partial is 2 x chunks^2 granule loads per channel and round of polling (4 KB per block and round at 256 blocks).
+    const int n2 = 2 * p.chunks;
+    bn_gu64* gr = (bn_gu64*)(p.sync + (long long)c * (n2 + 2));
     const unsigned long long tag = (unsigned long long)p.epoch << 32;
+    const bool two_level = p.chunks > kFusedFlatChunks;
+    const bool summer = !two_level || chunk == p.chunks - 1;
     if (threadIdx.x == 0) {
         __hip_atomic_store(gr + chunk * 2 + 0, tag | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(gr + chunk * 2 + 1, tag | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x < 64) {          // ONE wave polls; lane l takes granules l, l + 64, ... - all loads of a round in flight together
-        const int lane = (int)threadIdx.x, n2 = 2 * p.chunks;
+    if (threadIdx.x < 64 && summer) {   // ONE wave polls; lane l takes granules l, l + 64, ... - all loads of a round in flight together
+        const int lane = (int)threadIdx.x;
         unsigned long long v[kFusedPollMax];
 #pragma unroll
         for (int j = 0; j < kFusedPollMax; ++j)
@@ -635,12 +646,28 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedPar
             if (lane + 64 * j < n2) acc += (double)__uint_as_float((unsigned)v[j]);
 #pragma unroll
         for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane < 2) tot[lane] = acc;
+        if (lane < 2) {
+            tot[lane] = (float)acc;
+            if (two_level && !failed)
+                __hip_atomic_store(gr + n2 + lane, tag | __float_as_uint((float)acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0 && failed && p.status) atomicExch(p.status, (int)p.epoch);
+    } else if (threadIdx.x < 64) {      // the others: the two totals only
+        const int lane = (int)threadIdx.x;
+        unsigned long long v = lane < 2 ? __hip_atomic_load(gr + n2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        unsigned spins = 0;
+        while (!__all((v >> 32) == p.epoch)) {
+            if (++spins > p.spin_limit) { failed = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+            if (lane < 2 && (v >> 32) != p.epoch)
+                v = __hip_atomic_load(gr + n2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < 2) tot[lane] = __uint_as_float((unsigned)v);
         if (lane == 0 && failed && p.status) atomicExch(p.status, (int)p.epoch);
     }
     __syncthreads();
     const bool bad = failed != 0;
-    const float S1f = (float)tot[0], S2f = (float)tot[1];
+    const float S1f = tot[0], S2f = tot[1];
     if (chunk == 0 && threadIdx.x == 0) {
         const float nanv = __uint_as_float(0x7fc00000u);
         p.sum_dy[c] = bad ? nanv : S1f;
@@ -848,7 +875,7 @@ extern "C" size_t dcfp_bn_bwd_fused_sync_bytes(int N, int C, int HW) {
     const BnPlan p = bn_plan(N, C, HW);
     if (p.chunks > kFusedMaxChunks || p.chunk_elems > kChunkElems) return 0;
     if ((long long)C * p.chunks > 0x7fffffffLL) return 0;
-    return (size_t)C * p.chunks * 2 * sizeof(unsigned long long);
+    return (size_t)C * (p.chunks * 2 + 2) * sizeof(unsigned long long);     // per channel: the partials + the two totals
 }
 
 extern "C" int dcfp_bn_bwd_fused_f32(const float* dy, int64_t dy_nstride, const float* x, const float* y,
@@ -882,8 +909,8 @@ extern "C" int dcfp_bn_bwd_fused_f32(const float* dy, int64_t dy_nstride, const 
     p.sync = static_cast<unsigned long long*>(sync); p.epoch = epoch;
     p.spin_limit = spin_limit ? spin_limit : (1u << 18); p.status = status;
     p.sum_dy = sum_dy; p.sum_dy_xmu = sum_dy_xmu; p.dgamma = dgamma; p.dbeta = dbeta;
-    const dim3 grid((unsigned)((long long)C * pl.chunks));
     const size_t lds = 0;
+    const dim3 grid((unsigned)((long long)C * pl.chunks));
 #define LAUNCH_FUSED(R)                                                                                        \
     do {                                                                                                       \
         if (d_residual) hipLaunchKernelGGL((bn_bwd_fused_kernel<R, true>), grid, dim3(kThreads), lds, dcfp_s(stream), p);  \
@@ -911,12 +938,10 @@ extern "C" int dcfp_bn_stats_from_partials_f32(const float* partials, int64_t sl
     DcfpBnRunning rn;
     if (run_arg(run, &rn)) return DCFP_E_BADDESC;
     if (reinterpret_cast<uintptr_t>(partials) & 7u) return DCFP_E_BADDESC;
-    if (C <= 128)
-        hipLaunchKernelGGL(bn_stats_from_partials_kernel<8>, dim3((unsigned)((C + 7) / 8)), dim3(kSfpThreads), 0,
-                           dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
-    else
-        hipLaunchKernelGGL(bn_stats_from_partials_kernel<32>, dim3((unsigned)((C + 31) / 32)), dim3(kSfpThreads), 0,
-                           dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
+    // 8 channels per block at every width (round 4: 128 threads per channel, two loads deep - 13.4 -> 8.9 us on 256 channels
+    // x 1024 slots against the 32-channel blocks, profiles/r04_sfp_ab.txt; 98 launches per step)
+    hipLaunchKernelGGL(bn_stats_from_partials_kernel<8>, dim3((unsigned)((C + 7) / 8)), dim3(kSfpThreads), 0,
+                       dcfp_s(stream), partials, (long long)slots, slot_count, C, mean, var, rn);
     DCFP_RETURN_LAUNCH();
 }
 

@@ -43,6 +43,8 @@ __device__ __forceinline__ u32x4 make_desc(const void* base, unsigned bytes) {  
 }
 
 constexpr int kStatFloats = 4 * 64 * 33 * 2;   // 4 waves x [64 rows][33] (sum, M2) pairs
+constexpr int kStatFloats2 = 4 * 32 * 32 * 2;  // 128-row tiles: 4 waves x [32 rows][32] pairs, columns rotated by the row (no pad:
+                                               // 48 KB of operand stages + these 32 KB are exactly half of the CU's 160 KB)
 
 // WPI: every image has its own weight copy (p.wp_nstride floats apart) - the batched GEMM of conv_winograd.hip,
 // a kernel instance of its own so that profiles tell it from the 1x1 convs
@@ -297,6 +299,52 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
                     });
                 }
             }
+            if constexpr (!ACC && TM == 2 && !FAN) {
+                if (p.stat_part) {
+                    // the same statistics from a 128-row tile (round 4): a wave owns 64 rows - row 2 * q + i for its 32 row
+                    // slots q = (r & 3) + 8 * (r >> 2) + 4 * lhi - and merges them in two passes (i = 0, 1) of 32 rows through
+                    // a [32][32] image whose columns are rotated by the row (conflict-free writes along a row and reads
+                    // down a column without the pad the 64-row image has: LDS is full); per row the arithmetic and its order
+                    // are those of the 256-row tile, lanes 0..31 merge one row each
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2* st = reinterpret_cast<f32x2*>(Ss) + wid * (32 * 32);
+                    float* sp = p.stat_part + ((long long)(nt * WN + wn) * p.M + m0 + wm * (TM * 32)) * 2;
+                    static_for<0, 2>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        static_for<0, 16>([&](auto r_) {
+                            constexpr int r = decltype(r_)::value;
+                            const float a0 = acc[i][0][r], a1 = acc[i][1][r], a2 = acc[i][2][r], a3 = acc[i][3][r];
+                            const float s4 = (a0 + a1) + (a2 + a3);
+                            const float mu = 0.25f * s4;
+                            const float d0 = a0 - mu, d1 = a1 - mu, d2 = a2 - mu, d3 = a3 - mu;
+                            f32x2 v = {s4, (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)};
+                            const int row = lhi * 16 + r;
+                            st[row * 32 + ((l31 + row) & 31)] = v;
+                        });
+                        const int rw = lane & 31;
+                        float S = 0.f, M2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) {
+                            const f32x2 v = st[rw * 32 + ((k + rw) & 31)];
+                            S += v.x; M2 += v.y;
+                        }
+                        const float mean = S * (1.0f / 128.0f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) {
+                            const float d = 0.25f * st[rw * 32 + ((k + rw) & 31)].x - mean;
+                            M2 += 4.0f * d * d;
+                        }
+                        if (lane < 32) {
+                            const int rr = lane & 15;
+                            const int row = 2 * ((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 4)) + i;
+                            sp[row * 2] = mean;
+                            sp[row * 2 + 1] = M2;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+            }
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 o_img + (long long)m0 * p.P + p0, 0, 0x7ffffffcu, 0x00020000);
             unsigned voff = (unsigned)((wm * (TM * 32) + TM * 4 * lhi) * p.P + wn * (TN * 32) + TN * l31) * 4u;
@@ -456,7 +504,9 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
             cus = 256;
     }
     const int p128 = p128_mode();
-    const bool half = !p.stat_part && p.Mpad % 256 == 0 && (p128 == 2 || (p128 == 1 && p.CkP <= 256));
+    static const bool half_stats = [] { const char* e = getenv("DCFP_IGEMM_P128_STATS"); return !e || atoi(e) != 0; }();
+    const bool half = (!p.stat_part || (half_stats && !p.accumulate && !p.fan_src && !p.wp_nstride)) && p.Mpad % 256 == 0 &&
+                      (p128 == 2 || (p128 == 1 && p.CkP <= 256));
     Igemm2Params q = p;
     if (half) q.tiles_m = p.tiles_m * 2;
     const long long groups = ((long long)p.tiles_n_total + 7) / 8;
@@ -471,7 +521,7 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
 #endif
     blocks = blocks / 8 * 8;                       // grid % 8 == 0 keeps a workgroup's tiles on one pixel-tile residue
     if (blocks < 8) blocks = total < 8 ? total : 8;
-    const size_t lds = (size_t)(2 * BK * (half ? 384 : 512) + (p.stat_part ? kStatFloats : 0)) * sizeof(float);
+    const size_t lds = (size_t)(2 * BK * (half ? 384 : 512) + (p.stat_part ? (half ? kStatFloats2 : kStatFloats) : 0)) * sizeof(float);
     auto launch = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -129,6 +129,29 @@ def whole_model(tag, model, backbone, N, H, W, align):
             res["state_keys"] = np.array(list(sd.keys()))
             res["state_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
             res["ignore_prune_layer"] = np.array(m.ignore_prune_layer)
+    # Round 4: the SAME fp32 reference code in four more summation orders (1 / 2 / 4 threads, oneDNN off) - only the two
+    # per-tensor gradient summaries.  One fp32 run is one draw of a tensor's fp32-vs-fp64 error (which near-zero
+    # pre-activations get the other ReLU mask); the per-tensor bound of tests/_parity.py takes the tensor's error as the
+    # largest of the five draws.  (Appended after the arrays above: those are what they were.)
+    variants = (("32t1", 1, True), ("32t2", 2, True), ("32t4", 4, True), ("32nodnn", 8, False))
+    for sfx, threads, dnn in variants:
+        torch.set_num_threads(threads)
+        torch.backends.mkldnn.enabled = dnn
+        torch.manual_seed(0)
+        m = build_ref(model, backbone, align, torch.float32)
+        m.train()
+        x = fill.closed_form_input(N, H, W, torch.float32)
+        lab = fill.closed_form_labels(N, H, W)
+        m(x, lab, deepsup=True)["loss"].backward()
+        grads = {k: p.grad.detach() for k, p in m.named_parameters()}
+        pnames = [k for k, _ in m.named_parameters()]
+        res["grad_l2:" + sfx] = np.array([float(grads[k].double().norm()) for k in pnames])
+        res["grad_proj:" + sfx] = np.array([
+            float((grads[k].double().reshape(-1) * torch.cos(0.37 * torch.arange(grads[k].numel(), dtype=torch.float64))).sum())
+            for k in pnames])
+    torch.set_num_threads(8)
+    torch.backends.mkldnn.enabled = True
+    res["fp32_variants"] = np.array(["32"] + [v[0] for v in variants])
     res["meta"] = np.array([N, H, W, int(align)])
     np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **res)
     print("wrote", tag, "loss32", res["loss32"], "loss64", res["loss64"])

@@ -79,9 +79,12 @@ def test_forward_backward_vs_reference_golden(cuda, capsys, tag, model_name, bac
     pn = g["param_names"].tolist()
     params = dict(m.named_parameters())
     mine = np.array([float(params[k].grad.double().norm()) for k in pn])
-    l64, l32 = g["grad_l2:64"], g["grad_l2:32"]
+    l64 = g["grad_l2:64"]
     rel = np.abs(mine - l64) / (np.abs(l64) + 1e-12)
-    ref_rel = np.abs(l32 - l64) / (np.abs(l64) + 1e-12)
+    # the reference's own fp32-vs-fp64 error of a tensor: the largest over its five fp32 summation orders (8 / 4 / 2 / 1
+    # threads, oneDNN off - oracle/make_golden.py); one fp32 run is a single draw of that error
+    variants = [str(v) for v in g["fp32_variants"]]
+    ref_rel = np.max([np.abs(g["grad_l2:" + v] - l64) for v in variants], axis=0) / (np.abs(l64) + 1e-12)
     # PER TENSOR (tests/_parity.py): a tensor passes iff its error is within max(floor, 3x the reference's own fp32-vs-fp64
     # error on that tensor); floor = min(5e-2, 3x the reference's worst tensor) - 1.5e-2 on `simple`, 5e-2 on v3
     check_per_tensor(rel, ref_rel, pn, f"{tag} gradient norms", capsys)
@@ -90,9 +93,9 @@ def test_forward_backward_vs_reference_golden(cuda, capsys, tag, model_name, bac
     proj = np.array([float((params[k].grad.double().reshape(-1) *
                             torch.cos(0.37 * torch.arange(params[k].numel(), dtype=torch.float64, device=cuda))).sum())
                      for k in pn])
-    p64, p32 = g["grad_proj:64"], g["grad_proj:32"]
+    p64 = g["grad_proj:64"]
     perr = np.abs(proj - p64) / (np.abs(l64) + 1e-12)
-    pref = np.abs(p32 - p64) / (np.abs(l64) + 1e-12)
+    pref = np.max([np.abs(g["grad_proj:" + v] - p64) for v in variants], axis=0) / (np.abs(l64) + 1e-12)
     check_rankwise(perr, pref, pn, f"{tag} gradient projections", capsys)     # (why rank-wise: tests/_parity.py)
     for key in ("backbone.conv1.0", "backbone.layer1.0.conv1", "backbone.layer2.0.conv2", "last_conv.6"):
         a = params[key + ".weight"].grad.double().cpu().numpy(); b = g[f"wgrad:{key}:64"]
