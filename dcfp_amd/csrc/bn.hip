@@ -30,9 +30,16 @@ struct BnPlan {
 constexpr int kChunkElems = 8192;
 
 BnPlan bn_plan(int N, int C, int HW) {
-    (void)C;
     const long long E = (long long)N * HW;
     long long chunks = (E + kChunkElems - 1) / kChunkElems;
+    if (E <= kChunkElems) {
+        // small populations (up to one full chunk): the split of rounds 1-3 - ~2048 elements per block, at most ~4096
+        // blocks in all; chunks of at most 8192 elements either way, which is all the fused backward asks for
+        const long long by_size = (E + 2047) / 2048;
+        long long by_grid = 4096 / (C > 0 ? C : 1);
+        if (by_grid < 1) by_grid = 1;
+        chunks = by_size < by_grid ? by_size : by_grid;
+    }
     if (chunks < 1) chunks = 1;
     long long ce = (E + chunks - 1) / chunks;
     ce = (ce + 1023) / 1024 * 1024;   // whole wave iterations (256 elements per wave): the bit-mask ReLU path needs them

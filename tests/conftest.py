@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle (torch intra-op threads) runs on the cores this process may use, not on every logical CPU of the
+    # host: a GPU box gives one job a 16-core share of a much larger machine, and an OpenMP team sized for the whole
+    # machine spends the oracle's time in contention (the R101 whole-iteration test took 112 ... 150 s by box).
+    if not os.environ.get("OMP_NUM_THREADS"):
+        try:
+            import torch
+            n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            torch.set_num_threads(max(1, min(n, 16)))
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")
