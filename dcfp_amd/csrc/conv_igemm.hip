@@ -65,7 +65,7 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
                   void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out = nullptr,
                   float* stat_part = nullptr, const float* scale = nullptr, const float* shift = nullptr,
-                  const float* residual = nullptr, int relu = 0);
+                  const float* residual = nullptr, int relu = 0, int wp_valid = 0);
 long long dcfp_wino_stat_slots(int N, int H, int W, int d);
 bool dcfp_stem_shape(const DcfpConvDesc* d);                                                            // conv_stem.hip
 int dcfp_stem_fwd(const DcfpConvDesc* d, const float* x, const float* w, const float* bias, float* y, long long y_nstride,
@@ -78,6 +78,7 @@ int dcfp_gemv_dgrad(const DcfpConvDesc* d, const float* dy, long long dy_nstride
                     hipStream_t stream);
 bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_nstride, int pitch);   // conv_winograd2.hip
 size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck);
+void dcfp_wino_fused_pads(int N, int H, int W, int d, int M, int Ck, int* CkP, int* Mpad);
 size_t dcfp_wino_xform_bytes(int N, int H, int W, int d, int C);
 bool dcfp_wgrad_is_winograd(const DcfpConvDesc* d);      // conv_wgrad.hip
 bool dcfp_wgrad_wants_xform(const DcfpConvDesc* d);
@@ -165,15 +166,38 @@ static int wino_kind(const DcfpConvDesc* d, int pass) {
 }
 static bool wino_pass(const DcfpConvDesc* d, int pass) { return wino_kind(d, pass) != 0; }
 
+// A Winograd pass that ALWAYS runs the fused kernel (conv_winograd2.hip) needs nothing in its workspace but the transformed
+// filters U (16/9 of the weights): like the permuted copies of the direct kernels they can be kept per conv, rebuilt for the
+// whole model by the multi-tensor refresh after an optimizer step and passed back with wp_valid = 1 - 86 filter-transform
+// launches of ~10 us per step otherwise (round 4).  Not the forward that leaves its transformed INPUT behind for a batched
+// weight gradient with more than 256 input channels (three passes, all scratch).  DCFP_WINO_KEEP_U=0: off.
+static bool wino_keeps_u(const DcfpConvDesc* d, int pass) {
+    static const bool on = [] { const char* e = getenv("DCFP_WINO_KEEP_U"); return !e || atoi(e) != 0; }();
+    if (!on || (pass != DCFP_CONV_FWD && pass != DCFP_CONV_DGRAD) || !wino_pass(d, pass)) return false;
+    const bool fwd = pass == DCFP_CONV_FWD;
+    const int M = fwd ? d->Cout : d->Cin, Ck = fwd ? d->Cin : d->Cout;
+    const int sp = fwd ? d->x_pitch : d->dy_pitch;
+    if (!dcfp_wino_fused_ok(d->N, d->H, d->W, d->dil, M, Ck, (long long)Ck * d->H * (sp ? sp : d->W), sp)) return false;
+    if (fwd && Ck > 256 && dcfp_wino_ok(d->N, d->H, d->W, d->dil, M, Ck) && dcfp_conv2d_xform_bytes(d) > 0) return false;
+    return true;
+}
+
 extern "C" int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK || pass == DCFP_CONV_WGRAD) return 0;
-    return wino_pass(d, pass) ? 1 : 0;
+    return (wino_pass(d, pass) && !wino_keeps_u(d, pass)) ? 1 : 0;
 }
 
 size_t dcfp_conv2d_fwd_dgrad_workspace_bytes_(const DcfpConvDesc* d, int pass) {
     if (check_desc(d) != DCFP_OK) return 0;
     if (const int wk = wino_kind(d, pass)) {
         const int M = pass == DCFP_CONV_FWD ? d->Cout : d->Cin, Ck = pass == DCFP_CONV_FWD ? d->Cin : d->Cout;
+        if (wino_keeps_u(d, pass)) {
+            // (a forward WITH bias of the same descriptor runs a direct kernel - dcfp_conv2d_fwd_f32_nchw - and builds its
+            //  permuted copy in whatever workspace it is handed: large enough for either)
+            const size_t u = dcfp_wino_fused_workspace_bytes(d->N, d->H, d->W, d->dil, M, Ck);
+            const size_t direct = dcfp_igemm2_workspace_bytes(9, M, Ck, (long long)d->N * d->H * d->W, 1);
+            return u > direct ? u : direct;
+        }
         return wk == 1 ? dcfp_wino_workspace_bytes(d->N, d->H, d->W, d->dil, M, Ck)
                        : dcfp_wino_fused_workspace_bytes(d->N, d->H, d->W, d->dil, M, Ck);
     }
@@ -288,7 +312,8 @@ extern "C" int dcfp_conv2d_fwd_f32_nchw(const DcfpConvDesc* d, const float* x, c
     if (!bias && wino_pass(d, DCFP_CONV_FWD))
         return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T,
                              0, y, y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout,
-                             d->Cin, d->H, d->W, d->dil, 0, workspace, workspace_bytes, dcfp_s(stream));
+                             d->Cin, d->H, d->W, d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, nullptr,
+                             nullptr, nullptr, nullptr, 0, (wp_valid && wino_keeps_u(d, DCFP_CONV_FWD)) ? 1 : 0);
     if (!bias && igemm3_ok(d->Cout, (long long)d->N * d->Hout * d->Wout, d->stride, 1))
         return dcfp_igemm3_run(x, (long long)d->Cin * d->H * d->W, w, d->Cin * T, T, bias, y,
                                y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
@@ -326,7 +351,8 @@ extern "C" int dcfp_conv2d_fwd_stats_f32_nchw(const DcfpConvDesc* d, const float
     if (wino_pass(d, DCFP_CONV_FWD))
         return dcfp_wino_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), d->x_pitch, w, d->Cin * T, T, 0, y,
                              y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N, d->Cout, d->Cin, d->H, d->W,
-                             d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, stat_partials);
+                             d->dil, 0, workspace, workspace_bytes, dcfp_s(stream), nullptr, stat_partials, nullptr, nullptr,
+                             nullptr, 0, (wp_valid && wino_keeps_u(d, DCFP_CONV_FWD)) ? 1 : 0);
     return dcfp_igemm2_run(x, (long long)d->Cin * d->H * (d->x_pitch ? d->x_pitch : d->W), w, d->Cin * T, T, nullptr, y,
                            y_nstride ? y_nstride : (long long)d->Cout * d->Hout * d->Wout, d->N,
                            d->Cout, d->Cin, T, d->H, d->W, d->Hout, d->Wout, d->stride, 1, -d->pad,
@@ -347,7 +373,8 @@ extern "C" int dcfp_conv2d_dgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
     if (wino_pass(d, DCFP_CONV_DGRAD))      // dx = conv(dy, w') with w'[ci][co] = w[co][ci] rotated by 180 degrees
         return dcfp_wino_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * (d->dy_pitch ? d->dy_pitch : d->Wout),
                              d->dy_pitch, w, T, d->Cin * T, 1, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin, d->Cout,
-                             d->H, d->W, d->dil, accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream));
+                             d->H, d->W, d->dil, accumulate ? 1 : 0, workspace, workspace_bytes, dcfp_s(stream), nullptr,
+                             nullptr, nullptr, nullptr, nullptr, 0, (wp_valid && wino_keeps_u(d, DCFP_CONV_DGRAD)) ? 1 : 0);
     if (igemm3_ok(d->Cin, (long long)d->N * d->H * d->W, 1, d->stride))
         return dcfp_igemm3_run(dy, dy_nstride ? dy_nstride : (long long)d->Cout * d->Hout * d->Wout, w,
                                T, d->Cin * T, nullptr, dx, (long long)d->Cin * d->H * d->W, d->N, d->Cin,
@@ -452,6 +479,18 @@ extern "C" int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntr
     if (rc) return rc;
     if (!e || (pass != DCFP_CONV_FWD && pass != DCFP_CONV_DGRAD)) return DCFP_E_BADDESC;
     const int T = d->KH * d->KW;
+    if (wino_pass(d, pass)) {
+        if (!wino_keeps_u(d, pass)) return DCFP_E_UNSUPPORTED;            // all scratch: nothing to keep
+        // the fused Winograd kernel's transformed filters: perm8 = 2 (forward) / 3 (dgrad: taps rotated by 180 degrees, the
+        // roles of the channel strides swapped) - one (c, m) pair per element of the refresh kernel
+        const bool fwd = pass == DCFP_CONV_FWD;
+        e->T = 16; e->M = fwd ? d->Cout : d->Cin; e->Ck = fwd ? d->Cin : d->Cout;
+        dcfp_wino_fused_pads(d->N, d->H, d->W, d->dil, e->M, e->Ck, &e->CkP, &e->Mpad);
+        e->sAm = fwd ? d->Cin * T : T; e->sAc = fwd ? T : d->Cin * T; e->perm8 = fwd ? 2 : 3;
+        const long long pairs = (long long)e->CkP * e->Mpad;
+        e->n_blocks = (pairs + DCFP_WP_BLOCK_ELEMS - 1) / DCFP_WP_BLOCK_ELEMS;
+        return DCFP_OK;
+    }
     if (pass == DCFP_CONV_FWD) {
         const long long px = (long long)d->N * d->Hout * d->Wout;
         if (igemm3_ok(d->Cout, px, d->stride, 1)) return DCFP_E_UNSUPPORTED;     // bf16x3 keeps its own split copy

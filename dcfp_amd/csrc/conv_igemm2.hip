@@ -56,8 +56,18 @@ permute_weights_multi_kernel(const DcfpWpEntry* __restrict__ table, int n) {
         if (table[mid].first_block <= blk) lo = mid; else hi = mid - 1;
     }
     const DcfpWpEntry e = table[lo];
-    const long long total = (long long)e.T * e.CkP * e.Mpad;
     const long long base = (blk - e.first_block) * kWpBlockElems;
+    if (e.perm8 >= 2) {       // transformed filters of a fused Winograd conv (conv_winograd2.hip): one (c, m) pair per element
+        const long long pairs = (long long)e.CkP * e.Mpad;
+#pragma unroll 1
+        for (int u = 0; u < kWpBlockElems / 256; ++u) {
+            const long long i = base + u * 256 + threadIdx.x;
+            if (i >= pairs) return;
+            wino_filter2_pair(e.w, e.sAm, e.sAc, e.perm8 == 3, e.M, e.Ck, e.Mpad, i, e.wp);
+        }
+        return;
+    }
+    const long long total = (long long)e.T * e.CkP * e.Mpad;
 #pragma unroll
     for (int u = 0; u < kWpBlockElems / 256; ++u) {
         const long long i = base + u * 256 + threadIdx.x;

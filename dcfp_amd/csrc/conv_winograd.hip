@@ -36,7 +36,7 @@ size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck
 int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                         float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
                         void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
-                        const float* scale, const float* shift, const float* residual, int relu);
+                        const float* scale, const float* shift, const float* residual, int relu, int wp_valid);
 
 namespace {
 
@@ -475,7 +475,7 @@ long long dcfp_wino_stat_slots(int N, int H, int W, int d) {
 int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                   float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
                   void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
-                  const float* scale, const float* shift, const float* residual, int relu) {
+                  const float* scale, const float* shift, const float* residual, int relu, int wp_valid) {
     const WinoPlan pl = wino_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace)) return DCFP_E_WORKSPACE;
     // The fused kernel (conv_winograd2.hip) where it measures faster than the three passes (same-box A/B,
@@ -494,7 +494,7 @@ int dcfp_wino_run(const float* in, long long in_nstride, int in_pitch, const flo
         if (stat_part && (!dcfp_wino_stat_slots(N, H, W, d) || accumulate)) return DCFP_E_UNSUPPORTED;
         return dcfp_wino_fused_run(in, in_nstride, in_pitch, w, sAm, sAc, flip, out, out_nstride, N, M, Ck, H, W, d,
                                    accumulate, workspace, workspace_bytes, stream, xform_out, stat_part, scale, shift,
-                                   residual, relu);
+                                   residual, relu, wp_valid);
     }
     if (!three_ok) return DCFP_E_UNSUPPORTED;
     if (workspace_bytes < dcfp_wino_workspace_bytes(N, H, W, d, M, Ck)) return DCFP_E_WORKSPACE;

@@ -489,38 +489,8 @@ __global__ void __launch_bounds__(256, 1) wino_fused_kernel(const WinoFusedParam
 __global__ void __launch_bounds__(256) wino_filter2_kernel(const float* __restrict__ w, int sAm, int sAc, int flip, int M,
                                                            int Ck, int CkP, int Mpad, float* __restrict__ Ug) {
     const long long total = (long long)CkP * Mpad;
-    const int mblocks = Mpad / 64;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int c = (int)(idx / Mpad), m = (int)(idx - (long long)c * Mpad);
-        float g[9];
-        if (m < M && c < Ck) {
-            const float* src = w + (long long)m * sAm + (long long)c * sAc;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) g[t] = src[flip ? 8 - t : t];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) g[t] = 0.f;
-        }
-        float r[4][3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
-            r[0][k] = g0;
-            r[1][k] = 0.5f * ((g0 + g2) + g1);
-            r[2][k] = 0.5f * ((g0 + g2) - g1);
-            r[3][k] = g2;
-        }
-        const int cb = c >> 3, cl = c & 7, mb = m >> 6, ml = m & 63;
-        float* dst = Ug + ((((long long)(cb * mblocks + mb) * 16) * 2 + (ml >> 5)) * 64 + (cl & 1) * 32 + (ml & 31)) * 4 + (cl >> 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a = r[i][0], b = r[i][1], cc = r[i][2];
-            dst[(4 * i + 0) * 512] = a;
-            dst[(4 * i + 1) * 512] = 0.5f * ((a + cc) + b);
-            dst[(4 * i + 2) * 512] = 0.5f * ((a + cc) - b);
-            dst[(4 * i + 3) * 512] = cc;
-        }
-    }
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        wino_filter2_pair(w, sAm, sAc, flip, M, Ck, Mpad, idx, Ug);      // (igemm2_common.h)
 }
 
 struct FusedPlan {
@@ -571,6 +541,12 @@ bool dcfp_wino_fused_ok(int N, int H, int W, int d, int M, int Ck, long long in_
     return fused_mode(N, H, W, d, Ck, in_nstride, pitch) >= 0;
 }
 
+// padded channel counts of the transformed-filter image (for dcfp_conv2d_wp_layout)
+void dcfp_wino_fused_pads(int N, int H, int W, int d, int M, int Ck, int* CkP, int* Mpad) {
+    const FusedPlan pl = fused_plan(N, H, W, d, M, Ck);
+    *CkP = pl.CkP; *Mpad = pl.Mpad;
+}
+
 size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck) {
     return (size_t)fused_plan(N, H, W, d, M, Ck).ug_floats * sizeof(float);
 }
@@ -578,7 +554,7 @@ size_t dcfp_wino_fused_workspace_bytes(int N, int H, int W, int d, int M, int Ck
 int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, const float* w, int sAm, int sAc, int flip,
                         float* out, long long out_nstride, int N, int M, int Ck, int H, int W, int d, int accumulate,
                         void* workspace, size_t workspace_bytes, hipStream_t stream, float* xform_out, float* stat_part,
-                        const float* scale, const float* shift, const float* residual, int relu) {
+                        const float* scale, const float* shift, const float* residual, int relu, int wp_valid) {
     const FusedPlan pl = fused_plan(N, H, W, d, M, Ck);
     if (!workspace || !dcfp_aligned16(workspace) || workspace_bytes < (size_t)pl.ug_floats * sizeof(float))
         return DCFP_E_WORKSPACE;
@@ -586,7 +562,7 @@ int dcfp_wino_fused_run(const float* in, long long in_nstride, int in_pitch, con
     const int mode = fused_mode(N, H, W, d, Ck, in_nstride, pitch);
     if (mode < 0) return DCFP_E_UNSUPPORTED;
     float* Ug = static_cast<float*>(workspace);
-    {
+    if (!wp_valid) {      // (valid: the caller kept U from an earlier call / the multi-tensor refresh and the weights are unchanged)
         long long b = ((long long)pl.CkP * pl.Mpad + 255) / 256;
         if (b > 4096) b = 4096;
         hipLaunchKernelGGL(wino_filter2_kernel, dim3((unsigned)b), dim3(256), 0, stream, w, sAm, sAc, flip, M, Ck, pl.CkP,

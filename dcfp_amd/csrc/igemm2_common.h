@@ -59,6 +59,44 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// One (input channel c, output channel m) pair of the fused Winograd kernels' transformed filters (conv_winograd2.hip):
+// Ug[cb][mb][xi][wm][lane][kk] = (G g G^T)[xi] of g = w[m * sAm + c * sAc + tap] (flip: 8 - tap), c = 8 cb + 2 kk + lane / 32,
+// m = 64 mb + 32 wm + lane % 32; zeros past M / Ck.  Shared by wino_filter2_kernel (one conv per launch) and the
+// multi-tensor refresh (permute_weights_multi_kernel, conv_igemm2.hip: every kept copy of a model in one launch).
+__device__ __forceinline__ void wino_filter2_pair(const float* __restrict__ w, int sAm, int sAc, int flip, int M, int Ck,
+                                                  int Mpad, long long idx, float* __restrict__ Ug) {
+    const int mblocks = Mpad / 64;
+    const int c = (int)(idx / Mpad), m = (int)(idx - (long long)c * Mpad);
+    float g[9];
+    if (m < M && c < Ck) {
+        const float* src = w + (long long)m * sAm + (long long)c * sAc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) g[t] = src[flip ? 8 - t : t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) g[t] = 0.f;
+    }
+    float r[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
+        r[0][k] = g0;
+        r[1][k] = 0.5f * ((g0 + g2) + g1);
+        r[2][k] = 0.5f * ((g0 + g2) - g1);
+        r[3][k] = g2;
+    }
+    const int cb = c >> 3, cl = c & 7, mb = m >> 6, ml = m & 63;
+    float* dst = Ug + ((((long long)(cb * mblocks + mb) * 16) * 2 + (ml >> 5)) * 64 + (cl & 1) * 32 + (ml & 31)) * 4 + (cl >> 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = r[i][0], b = r[i][1], cc = r[i][2];
+        dst[(4 * i + 0) * 512] = a;
+        dst[(4 * i + 1) * 512] = 0.5f * ((a + cc) + b);
+        dst[(4 * i + 2) * 512] = 0.5f * ((a + cc) - b);
+        dst[(4 * i + 3) * 512] = cc;
+    }
+}
+
 template <int T>
 struct Frag;
 template <>

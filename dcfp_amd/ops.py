@@ -251,14 +251,16 @@ def _wp_buffer(w, which, d, nbytes, variant=""):
     return buf, 0
 
 
-def _conv_workspace(w, which, d):
-    """(workspace, wp_valid) of a forward / dgrad call: the conv's own persistent Wp buffer, or - where the library
-    says the workspace is pure scratch (Winograd: transformed operands, hundreds of MB) - one buffer shared by all."""
+def _conv_workspace(w, which, d, variant=""):
+    """(workspace, wp_valid) of a forward / dgrad call: the conv's own persistent buffer (the permuted weight copy of a
+    direct kernel, or the transformed filters of a fused Winograd conv), or - where the library says the workspace is
+    pure scratch (three-pass Winograd: transformed operands, hundreds of MB) - one buffer shared by all.  variant: a
+    call that does not run what dcfp_conv2d_wp_layout describes for (d, which) keeps a copy of its own, rebuilt on demand."""
     L = _lib.lib()
     nbytes = L.dcfp_conv2d_workspace_bytes(C.byref(d), which)
     if L.dcfp_conv2d_workspace_is_scratch(C.byref(d), which):
         return _workspace("conv_scratch", nbytes, w.device), 0
-    return _wp_buffer(w, which, d, nbytes)
+    return _wp_buffer(w, which, d, nbytes, variant)
 
 
 def refresh_wp():
@@ -355,7 +357,10 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, bn_run
     if bias is not None:
         _require(bias, "bias"); bias = bias.contiguous()
     L = _lib.lib()
-    ws, valid = _conv_workspace(w, _lib.CONV_FWD, d)
+    # (a 3x3 conv WITH bias never runs as Winograd: where the same descriptor without bias does, the kept buffer holds
+    #  transformed filters, not the direct kernel's permuted copy - the biased call gets a copy of its own)
+    variant = "bias" if (bias is not None and d.KH == 3 and conv_kernel_name(d, _lib.CONV_FWD).startswith("winograd")) else ""
+    ws, valid = _conv_workspace(w, _lib.CONV_FWD, d, variant)
     if keep is not None and KEEP_XFORM and bias is None:
         # Winograd conv whose weight gradient is Winograd too: leave the transformed input in a buffer that `keep`
         # (a dict living in the autograd context) holds until the backward pass (conv2d_wgrad(..., xform=))

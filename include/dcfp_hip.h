@@ -100,7 +100,9 @@ typedef struct DcfpWpEntry {
     int64_t first_block;
     int64_t n_blocks;
     int32_t T, Ck, CkP, M, Mpad, sAm, sAc;
-    int32_t perm8;   /* rows of every 256-row tile permuted for the ragged-M kernel (position 8l+i <- channel 32i+l) */
+    int32_t perm8;   /* 1: rows of every 256-row tile permuted for the ragged-M kernel (position 8l+i <- channel 32i+l);
+                        2 / 3: not a permutation but the transformed filters G g G^T of a fused Winograd conv (forward /
+                        dgrad: T = 16, one (channel, filter) pair per element - dcfp_conv2d_workspace_is_scratch) */
 } DcfpWpEntry;
 int dcfp_conv2d_wp_layout(const DcfpConvDesc* d, int pass, DcfpWpEntry* entry);
 int dcfp_conv2d_permute_weights_multi_f32(const DcfpWpEntry* table, int n_entries, int64_t total_blocks,
@@ -113,7 +115,9 @@ int dcfp_conv2d_pitch_supported(const DcfpConvDesc* d);
 /* 1 when the pass's workspace is pure scratch (the Winograd path of conv_winograd.hip: transformed filters,
  * transformed input and the batched GEMM's output - up to a few GB for the ASPP branches): nothing in it survives
  * the call, `wp_valid` is ignored, and a caller should hand every such conv the SAME buffer instead of keeping one
- * per conv.  0: the workspace holds the permuted weight copy described under `wp_valid`. */
+ * per conv.  0: the workspace holds the permuted weight copy described under `wp_valid` - or, for a Winograd pass
+ * that always runs the fused kernel (round 4), nothing but its transformed filters (16/9 of the weights), kept, refreshed
+ * by dcfp_conv2d_permute_weights_multi_f32 and validated through `wp_valid` the same way. */
 int dcfp_conv2d_workspace_is_scratch(const DcfpConvDesc* d, int pass);
 
 /* Winograd convs (see dcfp_conv2d_workspace_is_scratch): forward and weight gradient transform the same input x

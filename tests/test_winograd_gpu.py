@@ -130,7 +130,11 @@ def test_winograd_forward_dgrad_vs_fp64_and_vs_direct(cuda):
         want = [True, True, True]
         assert [n.startswith("winograd_f2x2_3x3") for n in rec["kernels"]] == want, (k, rec["kernels"])
         assert not any(n.startswith("winograd") for n in ref["kernels"]), (k, ref["kernels"])
-        assert rec["scratch"] == [int(v) for v in want[:2]] and ref["scratch"] == [0, 0]
+        # a Winograd pass' workspace is pure scratch (three passes) or nothing but its kept transformed filters (the fused
+        # kernel, round 4: dcfp_conv2d_workspace_is_scratch == 0, wp_valid honoured); the direct kernels keep permuted copies
+        assert all(v in (0, 1) for v in rec["scratch"]) and ref["scratch"] == [0, 0]
+        if os.environ.get("DCFP_WINO_KEEP_U", "1") == "0":
+            assert rec["scratch"] == [1, 1]
         assert all(0.44 <= f <= 0.60 for f, v in zip(rec["frac"], want) if v), (k, rec["frac"])   # 16/36 x tile padding
         assert rec["slice_equal"] and rec["slice_untouched"] and rec["dgrad_slice_equal"] and rec["wgrad_slice_equal"], (k, rec)
         assert rec.get("pitched_equal", True), k
@@ -230,6 +234,58 @@ def test_narrow_layers_on_the_fused_winograd_kernel(cuda, shape):
         yf = ops.conv2d_fused_infer(x.to(cuda), wd, sc, sh, 1, d, d, rs, True)
         reff = torch.relu(ref * sc.cpu().double()[None, :, None, None] + sh.cpu().double()[None, :, None, None] + rs.cpu().double())
         assert emax(yf, reff) < 3e-6
+
+
+def test_kept_winograd_filters_follow_the_weights(cuda):
+    """The fused Winograd kernel's transformed filters are kept per conv (wp_valid) and rebuilt for every conv at once by
+    the multi-tensor refresh after an optimizer step (ops.refresh_wp): a second call on unchanged weights must give the
+    same bits without transforming again, an in-place weight edit must be noticed, and after a raw-pointer update (what
+    FusedSGD does: WEIGHT_EPOCH) + refresh the outputs must be those of the NEW weights - forward and dgrad (flipped taps)."""
+    import torch
+    import torch.nn.functional as F
+    if os.environ.get("DCFP_CONV_WINOGRAD", "1") == "0":
+        pytest.skip("Winograd switched off")
+    from dcfp_amd import ops, _lib
+    g = torch.Generator().manual_seed(31)
+    N, Cin, H, W, Cout, d = 2, 96, 96, 160, 200, 4          # (a NARROW shape: dilation 4 reads dense rows)
+    x = torch.randn(N, Cin, H, W, generator=g).to(cuda)
+    dy = torch.randn(N, Cout, H, W, generator=g).to(cuda)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(cuda)
+    desc = ops._desc(x.shape, w.shape, 1, d, d)
+    assert ops.conv_kernel_name(desc, _lib.CONV_FWD).startswith("winograd_f2x2_3x3")
+    L = _lib.lib()
+    import ctypes as C
+    if L.dcfp_conv2d_workspace_is_scratch(C.byref(desc), _lib.CONV_FWD):
+        pytest.skip("DCFP_WINO_KEEP_U=0: the transformed filters are scratch")
+
+    def both():
+        return ops.conv2d_fwd(x, w, None, 1, d, d), ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, d, d)
+
+    def ref(wt):
+        y = F.conv2d(x.double(), wt.double(), None, 1, d, d)
+        dx = torch.nn.grad.conv2d_input(x.shape, wt.double(), dy.double(), 1, d, d)
+        return y, dx
+
+    def close(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max()) < 1e-5
+    y0, dx0 = both()                       # builds the copies (wp_valid = 0)
+    y1, dx1 = both()                       # kept copies (wp_valid = 1)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    r = ref(w)
+    assert close(y0, r[0]) and close(dx0, r[1])
+    w.mul_(1.5)                            # torch sees this edit: the version counter invalidates the copies
+    y2, dx2 = both()
+    r = ref(w)
+    assert close(y2, r[0]) and close(dx2, r[1]) and not torch.equal(y2, y0)
+    # a raw-pointer update (FusedSGD writes through the arena): the epoch marks every copy stale, ONE launch rebuilds them
+    w.data.view(-1)[::7] += 0.01
+    w._version  # (the in-place add above bumped it too; the epoch is what FusedSGD relies on)
+    ops.WEIGHT_EPOCH[0] += 1
+    ops.refresh_wp()
+    y3, dx3 = both()                       # valid again: no transform inside the calls
+    r = ref(w)
+    assert close(y3, r[0]) and close(dx3, r[1])
+    torch.cuda.synchronize()
 
 
 # What the model still runs on the DIRECT 9-tap kernels with Winograd on (the dilation-36 forward / dgrad, the weight
