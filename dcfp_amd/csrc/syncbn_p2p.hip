@@ -75,7 +75,9 @@ syncbn_p2p_kernel(Peers peers, int world, int rank, unsigned seq, int cap, const
     // loads.  So "my row is visible" needs no L2 write-back (a release fence's buffer_wbl2 would flush whatever the
     // previous conv left dirty in this XCD's L2), only that the stores have been acknowledged: vmcnt(0) in every
     // lane, then the barrier, then the flags - which travel the same path to the same peer behind the rows.
-    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0) (expcnt / lgkmcnt left alone)
+    // (inline asm with a memory clobber, in EVERY storing wave: the guide's publish recipe - a builtin wait may be moved or
+    //  merged by the compiler, and the flag must not overtake the rows)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < world) {
         unsigned* f = reinterpret_cast<unsigned*>(entry_of(peers.box[tid], world, cap, slot, rank));

@@ -18,6 +18,7 @@ def pytest_configure(config):
             import torch
             n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             torch.set_num_threads(max(1, min(n, 16)))
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(n, 16)))      # (child processes of the multi-rank tests inherit it)
         except Exception:
             pass
 
