@@ -537,9 +537,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
 // Arithmetic and summation order are those of bn_bwd_reduce_partial_kernel + bn_pair_final_kernel + bn_bwd_apply_kernel
 // (same plan, same helpers): the results are the same bits as the two-kernel path's.
 typedef __attribute__((address_space(1))) unsigned long long bn_gu64;
-constexpr int kFusedPollMax = 8;                            // granules per polling lane
-constexpr int kFusedFlatChunks = 16;                        // up to here every block reads all partials of its channel
-constexpr int kFusedMaxChunks = 32 * kFusedPollMax;         // 256 blocks per channel = 2M elements (the stem at 4 x 512 x 1024)
+constexpr int kFusedMaxChunks = 256;                        // blocks per channel: 2M elements (the stem at 4 x 512 x 1024); two granules per polling thread
 constexpr int kFusedIters = kChunkElems / (4 * kThreads);   // 8 float4 per thread and tensor
 
 struct BnFusedParams {
@@ -553,11 +551,69 @@ struct BnFusedParams {
     float* sum_dy; float* sum_dy_xmu; float* dgamma; float* dbeta;
 };
 
+// The hand-off of the fused backward: block (c, chunk) publishes its two partial sums (t1, t2 valid in thread 0), the
+// channel's totals come back in tot[0..1] (as floats: what bn_pair_final_kernel writes); *failed is set when the wait gave up.
+// parts: 2 * kFusedMaxChunks floats of LDS.  Ends in a __syncthreads().
+// Channels of more than kFusedFlatChunks blocks meet in two levels: only the block of the LAST chunk (dispatched last, so it
+// rarely waits) reads all the partials; it publishes the two totals as granules of their own and the others poll just those -
+// every block reading every partial is 2 x chunks^2 granule loads per channel and round of polling (4 KB per block and round at
+// 256 blocks).  The block that reads the partials does so with ALL its threads, at most two granules each (both loads in
+// flight together; four registers - a polling wave holding eight granules per lane cost the kernel its fifth block per CU),
+// parks the values in LDS, and one wave adds them in bn_pair_final_kernel's order.
+__device__ __forceinline__ void bn_fused_handoff(const BnFusedParams& p, int c, int chunk, float t1, float t2, float* tot,
+                                                 int* failed, float* parts) {
+    const int n2 = 2 * p.chunks;
+    bn_gu64* gr = (bn_gu64*)(p.sync + (long long)c * (n2 + 2));
+    const unsigned long long tag = (unsigned long long)p.epoch << 32;
+    const bool two_level = p.chunks > kFusedFlatChunks;
+    const bool summer = !two_level || chunk == p.chunks - 1;          // (block-uniform)
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) {
+        __hip_atomic_store(gr + chunk * 2 + 0, tag | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gr + chunk * 2 + 1, tag | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (summer) {
+        const int q0 = tid, q1 = tid + kThreads;                       // n2 <= 2 * kThreads
+        unsigned long long v0 = q0 < n2 ? __hip_atomic_load(gr + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        unsigned long long v1 = q1 < n2 ? __hip_atomic_load(gr + q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        unsigned spins = 0;
+        while ((v0 >> 32) != p.epoch || (v1 >> 32) != p.epoch) {
+            if (++spins > p.spin_limit) { *failed = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+            if ((v0 >> 32) != p.epoch) v0 = __hip_atomic_load(gr + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v1 >> 32) != p.epoch) v1 = __hip_atomic_load(gr + q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (q0 < n2) parts[q0] = __uint_as_float((unsigned)v0);
+        if (q1 < n2) parts[q1] = __uint_as_float((unsigned)v1);
+        __syncthreads();
+        if (tid < 64) {               // the channel's sums: bn_pair_final_kernel's order (wave_pair_totals)
+            const double acc = wave_pair_totals(n2, tid, [&](int j) { return parts[tid + 64 * j]; });
+            if (tid < 2) {
+                tot[tid] = (float)acc;
+                if (two_level && !*failed)
+                    __hip_atomic_store(gr + n2 + tid, tag | __float_as_uint((float)acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else if (tid < 2) {             // the others: the two totals only
+        unsigned long long v = __hip_atomic_load(gr + n2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((v >> 32) != p.epoch) {
+            if (++spins > p.spin_limit) { *failed = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+            v = __hip_atomic_load(gr + n2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tot[tid] = __uint_as_float((unsigned)v);
+    }
+    __syncthreads();
+    if (tid == 0 && *failed && p.status) atomicExch(p.status, (int)p.epoch);
+}
+
 template <int RELU, bool DRES>
 __global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedParams p) {
     __shared__ float red[4];
     __shared__ float tot[2];
     __shared__ int failed;
+    __shared__ float parts[2 * kFusedMaxChunks];
     const int c = blockIdx.x / p.chunks, chunk = blockIdx.x - c * p.chunks;
     const int HW = p.HW, C = p.C;
     const float mu = p.mean[c];
@@ -614,65 +670,7 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedPar
     const float t1 = block_sum_256(s1, red);
     const float t2 = block_sum_256(s2, red);
 
-    // ---- hand-off: publish the block's granules, collect the channel's.  Channels of more than kFusedFlatChunks blocks
-    // meet in two levels: only the block of the LAST chunk (dispatched last, so it rarely waits) reads all the partials; it
-    // publishes the two totals as granules of their own and the others poll just those - every block reading every
-    // partial is 2 x chunks^2 granule loads per channel and round of polling (4 KB per block and round at 256 blocks).
-    const int n2 = 2 * p.chunks;
-    bn_gu64* gr = (bn_gu64*)(p.sync + (long long)c * (n2 + 2));
-    const unsigned long long tag = (unsigned long long)p.epoch << 32;
-    const bool two_level = p.chunks > kFusedFlatChunks;
-    const bool summer = !two_level || chunk == p.chunks - 1;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(gr + chunk * 2 + 0, tag | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(gr + chunk * 2 + 1, tag | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < 64 && summer) {   // ONE wave polls; lane l takes granules l, l + 64, ... - all loads of a round in flight together
-        const int lane = (int)threadIdx.x;
-        unsigned long long v[kFusedPollMax];
-#pragma unroll
-        for (int j = 0; j < kFusedPollMax; ++j)
-            v[j] = lane + 64 * j < n2 ? __hip_atomic_load(gr + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-        unsigned spins = 0;
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < kFusedPollMax; ++j) ok &= (v[j] >> 32) == p.epoch;
-            if (__all(ok)) break;
-            if (++spins > p.spin_limit) { failed = 1; break; }          // (wave-uniform: every lane counts the same rounds)
-            __builtin_amdgcn_s_sleep(4);
-#pragma unroll
-            for (int j = 0; j < kFusedPollMax; ++j)
-                if ((v[j] >> 32) != p.epoch)
-                    v[j] = __hip_atomic_load(gr + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // the channel's sums: bn_pair_final_kernel's order
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < kFusedPollMax; ++j)
-            if (lane + 64 * j < n2) acc += (double)__uint_as_float((unsigned)v[j]);
-#pragma unroll
-        for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane < 2) {
-            tot[lane] = (float)acc;
-            if (two_level && !failed)
-                __hip_atomic_store(gr + n2 + lane, tag | __float_as_uint((float)acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0 && failed && p.status) atomicExch(p.status, (int)p.epoch);
-    } else if (threadIdx.x < 64) {      // the others: the two totals only
-        const int lane = (int)threadIdx.x;
-        unsigned long long v = lane < 2 ? __hip_atomic_load(gr + n2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-        unsigned spins = 0;
-        while (!__all((v >> 32) == p.epoch)) {
-            if (++spins > p.spin_limit) { failed = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-            if (lane < 2 && (v >> 32) != p.epoch)
-                v = __hip_atomic_load(gr + n2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane < 2) tot[lane] = __uint_as_float((unsigned)v);
-        if (lane == 0 && failed && p.status) atomicExch(p.status, (int)p.epoch);
-    }
-    __syncthreads();
+    bn_fused_handoff(p, c, chunk, t1, t2, tot, &failed, parts);
     const bool bad = failed != 0;
     const float S1f = tot[0], S2f = tot[1];
     if (chunk == 0 && threadIdx.x == 0) {

@@ -74,9 +74,9 @@ def test_fused_equals_two_kernel_path(cuda, shape):
     ops.check_fused_status()
 
 
-def test_fused_pitched_dx_and_strided_dy(cuda):
+@pytest.mark.parametrize("shape", [(2, 12, 32, 64), (2, 8, 64, 128)])     # (one chunk per channel; two full chunks)
+def test_fused_pitched_dx_and_strided_dy(cuda, shape):
     from dcfp_amd import ops
-    shape = (2, 12, 32, 64)
     N, C, H, W = shape
     x, _, gamma, beta, _ = _inputs(shape, cuda, 5)
     g = torch.Generator().manual_seed(6)
@@ -85,6 +85,7 @@ def test_fused_pitched_dx_and_strided_dy(cuda):
     mean, var = ops.bn_stats(x)
     pa = ops.pitched_buffer(shape, W + 4, "t_fused_a", cuda)
     pb = ops.pitched_buffer(shape, W + 4, "t_fused_b", cuda)
+    pa.zero_(); pb.zero_()
     a = _two_kernel(ops, dy, x, None, mean, var, gamma, beta, 2, False, dx_out=pa)
     b = _fused(ops, dy, x, None, mean, var, gamma, beta, 2, False, dx_out=pb)
     _same(a[:4], b[:4], "sums")
