@@ -538,6 +538,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, long long dy_nstride,
 // (same plan, same helpers): the results are the same bits as the two-kernel path's.
 typedef __attribute__((address_space(1))) unsigned long long bn_gu64;
 constexpr int kFusedMaxChunks = 256;                        // blocks per channel: 2M elements (the stem at 4 x 512 x 1024); two granules per polling thread
+constexpr int kFusedFlatChunks = 16;                        // up to here every block reads all partials of its channel
 constexpr int kFusedIters = kChunkElems / (4 * kThreads);   // 8 float4 per thread and tensor
 
 struct BnFusedParams {
@@ -701,6 +702,93 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_fused_kernel(const BnFusedPar
             else *reinterpret_cast<float4*>(dxr + ii[k]) = o;
             if (DRES) *reinterpret_cast<float4*>(p.dres + row * HW + ii[k]) = g[k];
         }
+    }
+}
+
+// ---- the same for blocks that lie inside ONE image (HW a multiple of the chunk, every chunk full: every BatchNorm of the
+// model at 1024 x 2048): image, channel and chunk give block-uniform base pointers, a thread's eight float4 sit 4 KB
+// apart from one lane offset, nothing is predicated - under 96 registers, FIVE blocks per CU instead of four.
+template <int RELU, bool DRES, bool PITCH>
+__global__ void __launch_bounds__(kThreads, 5) bn_bwd_fusedu_kernel(const BnFusedParams p) {
+    __shared__ float red[4];
+    __shared__ float tot[2];
+    __shared__ int failed;
+    __shared__ float parts[2 * kFusedMaxChunks];
+    const int c = blockIdx.x / p.chunks, chunk = blockIdx.x - c * p.chunks;
+    const int HW = p.HW, C = p.C;
+    const float mu = p.mean[c];
+    const float istd = 1.0f / sqrtf(p.var[c] + p.eps);
+    const float gm = p.gamma[c];
+    const float bt = RELU == 2 ? p.beta[c] : 0.f;
+    const int e0 = chunk * kChunkElems;
+    const int n = e0 / HW, i0 = e0 - n * HW;                     // block-uniform: the chunk lies inside image n
+    const long long row = (long long)n * C + c;
+    const float* dyb = p.dy + (long long)n * p.dy_nstride + (long long)c * HW + i0;
+    const float* xb = p.x + row * HW + i0;
+    const unsigned lo = 4u * threadIdx.x;
+    if (threadIdx.x == 0) failed = 0;
+
+    float4 g[kFusedIters], xv[kFusedIters];
+#pragma unroll
+    for (int k = 0; k < kFusedIters; ++k) {
+        g[k] = *reinterpret_cast<const float4*>(dyb + 4 * kThreads * k + lo);
+        xv[k] = *reinterpret_cast<const float4*>(xb + 4 * kThreads * k + lo);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kFusedIters; ++k) {
+        if (RELU == 1) {
+            const float4 yv = *reinterpret_cast<const float4*>(p.y + (long long)n * p.y_nstride + (long long)c * HW + i0 +
+                                                               4 * kThreads * k + lo);
+            g[k].x = yv.x > 0.f ? g[k].x : 0.f; g[k].y = yv.y > 0.f ? g[k].y : 0.f;
+            g[k].z = yv.z > 0.f ? g[k].z : 0.f; g[k].w = yv.w > 0.f ? g[k].w : 0.f;
+        } else if (RELU == 2) {
+            g[k].x = bn_val(xv[k].x, mu, istd, gm, bt) > 0.f ? g[k].x : 0.f;
+            g[k].y = bn_val(xv[k].y, mu, istd, gm, bt) > 0.f ? g[k].y : 0.f;
+            g[k].z = bn_val(xv[k].z, mu, istd, gm, bt) > 0.f ? g[k].z : 0.f;
+            g[k].w = bn_val(xv[k].w, mu, istd, gm, bt) > 0.f ? g[k].w : 0.f;
+        } else if (RELU == 3) {
+            // a wave iteration covers 256 consecutive pixels: words 4 * (i / 256) + 0..3 of the (n, c) row, bit = lane
+            const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(p.y) + row * (long long)(HW >> 6) +
+                                           ((i0 + 4 * kThreads * k + 256 * (int)(threadIdx.x >> 6)) >> 8) * 4;
+            const int sh = (int)(threadIdx.x & 63);
+            g[k].x = ((mw[0] >> sh) & 1ull) ? g[k].x : 0.f; g[k].y = ((mw[1] >> sh) & 1ull) ? g[k].y : 0.f;
+            g[k].z = ((mw[2] >> sh) & 1ull) ? g[k].z : 0.f; g[k].w = ((mw[3] >> sh) & 1ull) ? g[k].w : 0.f;
+        }
+        bwd_accumulate(g[k], xv[k], mu, s1, s2);
+    }
+    const float t1 = block_sum_256(s1, red);
+    const float t2 = block_sum_256(s2, red);
+    bn_fused_handoff(p, c, chunk, t1, t2, tot, &failed, parts);
+    const bool bad = failed != 0;
+    const float S1f = tot[0], S2f = tot[1];
+    const float nanv = __uint_as_float(0x7fc00000u);
+    if (chunk == 0 && threadIdx.x == 0) {
+        p.sum_dy[c] = bad ? nanv : S1f;
+        p.sum_dy_xmu[c] = bad ? nanv : S2f;
+        if (p.dgamma) p.dgamma[c] = bad ? nanv : S2f * rsqrtf(p.var[c] + p.eps);
+        if (p.dbeta) p.dbeta[c] = bad ? nanv : S1f;
+    }
+    const float mean_dy = S1f * p.inv_count;
+    const float kk = S2f * p.inv_count * istd * istd;
+    const float gi = bad ? nanv : gm * istd;
+    float* dxb = p.dx + row * (PITCH ? (long long)(HW / p.W) * p.dx_pitch : (long long)HW) + (PITCH ? 0 : i0);
+    float* drb = DRES ? p.dres + row * HW + i0 : nullptr;
+#pragma unroll
+    for (int k = 0; k < kFusedIters; ++k) {
+        float4 o;
+        o.x = bwd_dx(g[k].x, xv[k].x, mu, mean_dy, kk, gi);
+        o.y = bwd_dx(g[k].y, xv[k].y, mu, mean_dy, kk, gi);
+        o.z = bwd_dx(g[k].z, xv[k].z, mu, mean_dy, kk, gi);
+        o.w = bwd_dx(g[k].w, xv[k].w, mu, mean_dy, kk, gi);
+        if (PITCH) {
+            const int i = i0 + 4 * kThreads * k + (int)lo;
+            const int h = i / p.W;
+            *reinterpret_cast<float4*>(dxb + h * p.dx_pitch + (i - h * p.W)) = o;
+        } else {
+            *reinterpret_cast<float4*>(dxb + 4 * kThreads * k + lo) = o;
+        }
+        if (DRES) *reinterpret_cast<float4*>(drb + 4 * kThreads * k + lo) = g[k];
     }
 }
 
@@ -916,6 +1004,20 @@ extern "C" int dcfp_bn_bwd_fused_f32(const float* dy, int64_t dy_nstride, const 
     p.sum_dy = sum_dy; p.sum_dy_xmu = sum_dy_xmu; p.dgamma = dgamma; p.dbeta = dbeta;
     const size_t lds = 0;
     const dim3 grid((unsigned)((long long)C * pl.chunks));
+    // blocks inside one image, every chunk full: the low-register kernel (DCFP_BN_FUSED_UNI=0: the general one)
+    static const bool uni_on = [] { const char* e = getenv("DCFP_BN_FUSED_UNI"); return !e || atoi(e) != 0; }();
+    if (uni_on && pl.chunk_elems == kChunkElems && HW % kChunkElems == 0) {
+#define LAUNCH_FUSEDU2(R, D, P) hipLaunchKernelGGL((bn_bwd_fusedu_kernel<R, D, P>), grid, dim3(kThreads), lds, dcfp_s(stream), p)
+#define LAUNCH_FUSEDU(R)                                                                                       \
+    do {                                                                                                       \
+        if (d_residual) { if (dx_pitch) LAUNCH_FUSEDU2(R, true, true); else LAUNCH_FUSEDU2(R, true, false); }  \
+        else { if (dx_pitch) LAUNCH_FUSEDU2(R, false, true); else LAUNCH_FUSEDU2(R, false, false); }           \
+    } while (0)
+        if (relu == 3) LAUNCH_FUSEDU(3); else if (relu == 2) LAUNCH_FUSEDU(2); else if (relu == 1) LAUNCH_FUSEDU(1); else LAUNCH_FUSEDU(0);
+#undef LAUNCH_FUSEDU
+#undef LAUNCH_FUSEDU2
+        DCFP_RETURN_LAUNCH();
+    }
 #define LAUNCH_FUSED(R)                                                                                        \
     do {                                                                                                       \
         if (d_residual) hipLaunchKernelGGL((bn_bwd_fused_kernel<R, true>), grid, dim3(kThreads), lds, dcfp_s(stream), p);  \
