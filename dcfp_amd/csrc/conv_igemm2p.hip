@@ -504,9 +504,15 @@ int dcfp_igemm2p_launch(const Igemm2Params& p, hipStream_t stream) {
             cus = 256;
     }
     const int p128 = p128_mode();
-    static const bool half_stats = [] { const char* e = getenv("DCFP_IGEMM_P128_STATS"); return !e || atoi(e) != 0; }();
-    const bool half = (!p.stat_part || (half_stats && !p.accumulate && !p.fan_src && !p.wp_nstride)) && p.Mpad % 256 == 0 &&
-                      (p128 == 2 || (p128 == 1 && p.CkP <= 256));
+    // launches WITH the statistics epilogue take the 128-row tiles at EVERY K (DCFP_IGEMM_P128_STATS: 0 never, 1 K <= 256 only,
+    // 2 always - the default): with one workgroup per CU that epilogue (2...3 us of vector ALU per 256 x 256 tile) is exposed, with
+    // two it runs under the other workgroup's MFMAs - 512 -> 2048 forward 2.150 -> 2.027 ms, 1024 -> 256 0.526 -> 0.504 ms
+    // (profiles/r04_p128_stats_ab.txt), although the same GEMMs WITHOUT the epilogue are 5...9 % slower on 128-row tiles at K >= 512
+    static const int half_stats = [] { const char* e = getenv("DCFP_IGEMM_P128_STATS"); return e ? atoi(e) : 2; }();
+    const bool k_ok = p128 == 2 || (p128 == 1 && p.CkP <= 256);
+    const bool half = p.Mpad % 256 == 0 &&
+                      (p.stat_part ? (!p.accumulate && !p.fan_src && !p.wp_nstride && (half_stats == 2 || (half_stats == 1 && k_ok)))
+                                   : k_ok);
     Igemm2Params q = p;
     if (half) q.tiles_m = p.tiles_m * 2;
     const long long groups = ((long long)p.tiles_n_total + 7) / 8;
