@@ -482,9 +482,12 @@ __global__ void __launch_bounds__(256, TM_ == 2 ? 2 : 1) igemm2_dma1p_kernel(con
 
 }  // namespace
 
-// 128-row tiles, two workgroups per CU: DCFP_IGEMM_P128 = 0 off, 1 the K <= 256 problems (default), 2 all
+// 128-row tiles, two workgroups per CU: DCFP_IGEMM_P128 = 0 off, 1 the K <= 256 problems (the default of rounds 2-3, when the
+// long-K layers measured 5...9 % slower on them), 2 all (default since the end of round 4: with the leaner loader of round 4
+// every 1x1 forward / dgrad entry of the step is faster or equal on them - the M = 256, K = 1024 dgrads 11.74 -> 11.29 ms, the
+// K = 512 fan-in dgrads of layer4 4.63 -> 4.19 ms, 1.6 ms per step in all: profiles/r04_p128_all_ab.txt)
 static int p128_mode() {
-    static const int p128 = [] { const char* e = getenv("DCFP_IGEMM_P128"); return e ? atoi(e) : 1; }();
+    static const int p128 = [] { const char* e = getenv("DCFP_IGEMM_P128"); return e ? atoi(e) : 2; }();
     return p128;
 }
 // the fan-in launch of (Mpad, CkP) takes the 128-row tiles - the only ones with the BatchNorm-sums side output
