@@ -456,9 +456,14 @@ int num_cus() {
 // 128- / 64-row tile).  Same staging, same K order per output element as the 2 x 2 layout.
 // BATCH: p.batch independent problems in one launch (the Winograd weight gradient's 16 components) - an instance of
 // its own so that profiles tell it from the 1x1 convs' weight gradients
-template <int TAPS, bool MIXED, bool WIDE = false, bool BATCH = false>
-__global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
-    constexpr int TM = WIDE ? 8 : 4, TN = WIDE ? 2 : 4, WN = WIDE ? 4 : 2, BM = 256, BN = 256;
+// HALF (end of round 4, 1x1 convs): 128 rows of dy per tile - 128 accumulator registers, TWO workgroups per CU, each wave
+// 64 x 128 - the arrangement that beat one 256-row workgroup per CU on every 1x1 forward / dgrad (section 3g); same splits, same
+// K order per output element: the same bits as the 256-row tile.
+template <int TAPS, bool MIXED, bool WIDE = false, bool BATCH = false, bool HALF = false>
+__global__ void __launch_bounds__(256, HALF ? 2 : 1) wgrad_dma_kernel(const WgradParams p) {
+    static_assert(!HALF || (TAPS == 1 && !MIXED && !WIDE), "the 128-row tile is built for the 1x1 burst loader only");
+    constexpr int TM = WIDE ? 8 : (HALF ? 2 : 4), TN = WIDE ? 2 : 4, WN = WIDE ? 4 : 2, BM = HALF ? 128 : 256, BN = 256;
+    constexpr int AW = BM / 4, AQ = BM / 64;      // dy rows a wave copies per K-step, in AQ instructions of 16 rows
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][BK]
     float* Bs = smem + 2 * BM * BK;     // [2][BN][BK]
@@ -515,10 +520,10 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     // ---- A (dy): instruction q of this wave copies rows 64*wid + 16q + (lane >> 2); the lane's slot
     // lane & 3 receives pixel quad (lane & 3) ^ ((lane >> 4) & 3)
     const int gq = (lane & 3) ^ ((lane >> 4) & 3);
-    unsigned a_voff[4];
+    unsigned a_voff[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int m = m0 + 64 * wid + 16 * q + (lane >> 2);
+    for (int q = 0; q < AQ; ++q) {
+        int m = m0 + AW * wid + 16 * q + (lane >> 2);
         m = m < p.M ? m : p.M - 1;
         a_voff[q] = (unsigned)(m * dyP + 4 * gq) * 4u;
     }
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
         constexpr int q = decltype(q_)::value;
         // (uniform values; readfirstlane makes the compiler keep them in SGPRs for the asm operands)
         const unsigned a_s = __builtin_amdgcn_readfirstlane((unsigned)(c_im * (int)p.dy_nstride + c_oh * p.dy_pitch + c_ow) * 4u);
-        const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BM + 64 * wid + 16 * q) * BK) * 4u);
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)((buf * BM + AW * wid + 16 * q) * BK) * 4u);
         const unsigned av = a_voff[q], as_ = a_s;
         const u32x4 ad = a_desc;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -612,7 +617,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     unsigned a1_run = 0, b1_run = 0;
     const unsigned a1_row = (unsigned)(p.dy_pitch - p.Wo) * 4u, b1_row = (unsigned)(p.x_pitch - p.W) * 4u;
     const unsigned a1_img = (unsigned)((int)p.dy_nstride - p.Ho * p.dy_pitch) * 4u, b1_img = (unsigned)((int)p.x_nstride - p.H * p.x_pitch) * 4u;
-    const unsigned lds_a_w = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)(64 * wid * BK) * 4u);
+    const unsigned lds_a_w = __builtin_amdgcn_readfirstlane(lds_a0 + (unsigned)(AW * wid * BK) * 4u);
     const unsigned lds_b_w = __builtin_amdgcn_readfirstlane(lds_b0 + (unsigned)(64 * wid * BK) * 4u);
     if constexpr (TAPS == 1 && !MIXED) {
 #pragma unroll
@@ -622,7 +627,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WgradParams p) {
     }
     auto issue1 = [&](int buf) {
         const unsigned abuf = lds_a_w + (buf ? (unsigned)(BM * BK) * 4u : 0u), bbuf = lds_b_w + (buf ? (unsigned)(BN * BK) * 4u : 0u);
-        static_for<0, 4>([&](auto q_) {
+        static_for<0, AQ>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             const unsigned av = a_voff[q], base = abuf, run = a1_run;
             const u32x4 ad = a_desc;
@@ -749,6 +754,7 @@ struct Plan {
     int bm, bn, cfg;  // cfg: 0 = 256x256, 1 = 128x256, 2 = 64x64 (one wave), 3 = 256x128, 4 = 256x64
     int tiles_m, tiles_n, splits, kchunk;
     bool wide;        // 256 x 256 tile on wgrad_dma_kernel<.., WIDE>: dead dy row blocks skipped (ragged / small Cout)
+    bool half;        // 128 x 256 tile on wgrad_dma_kernel<1, .., HALF>: two workgroups per CU (1x1 convs, Cout % 128 == 0)
 };
 
 static bool math_bf16x3();
@@ -798,6 +804,13 @@ Plan make_plan(const DcfpConvDesc* d) {
             }
         }
     }
+    pl.half = false;
+    {
+        static const bool on = [] { const char* e = getenv("DCFP_WGRAD_HALF"); return !e || atoi(e) != 0; }();   // =0: off
+        if (on && pl.cfg == 0 && !pl.wide && d->KH == 1 && M % 128 == 0 && !math_bf16x3() && dma_geometry(d)) {
+            pl.half = true; pl.bm = 128;
+        }
+    }
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (Nn + pl.bn - 1) / pl.bn;
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
@@ -807,7 +820,7 @@ Plan make_plan(const DcfpConvDesc* d) {
     // count wastes most of a round (513 blocks on 256 CUs took 1.35x the time of 252).
     const int cus = num_cus();
     // resident workgroups per CU (accumulator registers per lane: 256 / 128 / 64 / 32)
-    const long long per_cu = pl.cfg == 2 ? 8 : pl.cfg == 0 ? 1 : 2;      // (cfg 5: 96 accumulator registers, 51 KB LDS: 2)
+    const long long per_cu = pl.cfg == 2 ? 8 : (pl.cfg == 0 && !pl.half) ? 1 : 2;      // (cfg 5: 96 accumulator registers, 51 KB LDS: 2)
     const long long slots = (long long)cus * per_cu;
     const long long max_splits = (Kpix + BK * 8 - 1) / (BK * 8);   // >= 8 K-steps per split
     long long splits = 1;
@@ -890,10 +903,10 @@ static bool wgrad_dma_ok(const DcfpConvDesc* d, int cfg) {
 }
 static bool wgrad_dma_mixed(const DcfpConvDesc* d) { return d->KH == 3 && ((d->pad | d->dil) & 3) != 0; }
 
-template <int TAPS, bool MIXED, bool WIDE = false, bool BATCH = false>
+template <int TAPS, bool MIXED, bool WIDE = false, bool BATCH = false, bool HALF = false>
 int launch_dma(const WgradParams& p, long long blocks, hipStream_t stream) {
-    const size_t lds = (size_t)2 * 512 * BK * sizeof(float);
-    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED, WIDE, BATCH>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    const size_t lds = (size_t)2 * (HALF ? 384 : 512) * BK * sizeof(float);
+    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS, MIXED, WIDE, BATCH, HALF>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DCFP_OK : (int)e;
 }
@@ -1200,7 +1213,7 @@ extern "C" int dcfp_conv2d_wgrad_f32_nchw(const DcfpConvDesc* d, const float* dy
         const long long blocks = (long long)pl.tiles_m * pl.tiles_n * pl.splits;
         if (blocks > 0x7fffffffLL) return DCFP_E_UNSUPPORTED;
         // (pitched x: every shifted quad reads data or the rows' zero tails - the un-mixed kernel does it all)
-        rc = T == 1 ? launch_dma<1, false>(p, blocks, dcfp_s(stream))
+        rc = T == 1 ? (pl.half ? launch_dma<1, false, false, false, true>(p, blocks, dcfp_s(stream)) : launch_dma<1, false>(p, blocks, dcfp_s(stream)))
                     : (wgrad_dma_mixed(d) && p.x_pitch == d->W) ? launch_dma<9, true>(p, blocks, dcfp_s(stream))
                                                                  : launch_dma<9, false>(p, blocks, dcfp_s(stream));
     } else
