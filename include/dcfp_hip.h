@@ -14,7 +14,10 @@
  *     The only process-wide state is a set of tuning switches read ONCE from the
  *     environment into function-local statics on first use: DCFP_CONV_MATH (bf16x3 opt-in),
  *     DCFP_CONV_WINOGRAD (0 direct kernels only / 1 cost model, default / 2 wherever eligible),
- *     DCFP_IGEMM_{DMA,DMA9,DMA8,2D,BK32,PERSIST,P128,TAPSKIP}, DCFP_WGRAD_{DMA,DMA_MIXED,WIDE,LOPSIDED,T192},
+ *     DCFP_IGEMM_{DMA,DMA9,DMA8,2D,BK32,PERSIST,P128,P128_STATS,TAPSKIP} (P128: 128-row tiles with two workgroups per CU for
+ *     the 1x1 forward / dgrad - 0 off / 1 K <= 256 / 2 every K, default; P128_STATS: the same for launches with the statistics
+ *     epilogue), DCFP_WGRAD_{DMA,DMA_MIXED,WIDE,LOPSIDED,T192,HALF} (HALF = 0: 1x1 weight gradients on 256-row tiles),
+ *     DCFP_WINO_KEEP_U (0: the fused Winograd kernels' transformed filters are scratch again, rebuilt in every call),
  *     DCFP_WINO_VEC, DCFP_WINO_FUSED (0 three-pass Winograd only / 1 fused kernel where it wins, default / 2 wherever it
  *     applies), DCFP_WINO_WGRAD_FUSED (0 batched Winograd weight gradient on the kept transform only / 1 the fused
  *     weight-gradient kernel where the cost model prefers it, default / 2 wherever it applies and beats the direct
