@@ -792,7 +792,10 @@ __global__ void __launch_bounds__(kThreads, 5) bn_bwd_fusedu_kernel(const BnFuse
     }
 }
 
-constexpr int kColsPerBlock = 4096;
+// elements of an (n, c) row per block of the apply kernels (DCFP_BN_COLS: multiples of 1024).  2048 since the end of round 4:
+// shorter blocks stream faster on this chip - forward apply 15.97 -> 15.31 ms per step (5.37 -> 5.60 TB/s; 1024: 14.97, the step
+// no better), 8192 / 16384 slower (profiles/r04_bn_cols_ab.txt)
+static const int kColsPerBlock = [] { const char* e = getenv("DCFP_BN_COLS"); const int v = e ? atoi(e) : 2048; return v >= 1024 && v % 1024 == 0 ? v : 2048; }();
 
 }  // namespace
 
