@@ -375,7 +375,7 @@ splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long 
     }
 }
 
-// the same sums (same order per element), four elements per thread and eight slabs' loads in flight
+// the same sums (same order per element), four elements per thread and sixteen / eight slabs' loads in flight
 __global__ void __launch_bounds__(256)
 splitk_reduce_vec4_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n4, long long n,
                           int splits) {
@@ -386,6 +386,13 @@ splitk_reduce_vec4_kernel(const float* __restrict__ ws, float* __restrict__ dw, 
     const long long slab = n / 4;
     f4 s = src[0];
     int k = 1;
+    for (; k + 16 <= splits; k += 16) {      // (16 slabs' loads in flight - the 1x1 weight gradients of layer3 have 64 slabs: 4 round trips)
+        f4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(long long)(k + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
     for (; k + 8 <= splits; k += 8) {
         f4 v[8];
 #pragma unroll
